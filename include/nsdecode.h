@@ -1,0 +1,227 @@
+/*
+ * nsdecode.h - C ABI of libnsdecode.so: the NeuroSymbolic (NS) beam scorer of
+ * Silent-Speech as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference implements this path in Python only; there is no native
+ * interface to bind.  Each entry point therefore cites the reference code
+ * whose work it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every pointer marked "device" is caller-owned HIP device memory
+ *     (e.g. torch.Tensor.data_ptr()); the library allocates device memory
+ *     only inside nsd_tables_create and frees it in nsd_tables_destroy;
+ *   - kernels are enqueued on the caller's stream and never synchronise;
+ *   - return value: 0 = NSD_OK, < 0 = argument error (NSD_E_*), > 0 = a
+ *     hipError_t value; nsd_strerror() describes all three;
+ *   - vocabulary layout is the reference TextTransform
+ *     (scripts/data_utils.py:44-50): ids 0-25 a-z, 26-35 0-9, 36 space,
+ *     37 BOS, 38 EOS, 39 PAD; V = 40.
+ */
+#ifndef NSDECODE_H
+#define NSDECODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSD_VERSION        100
+#define NSD_V              40
+#define NSD_NBASE          37
+#define NSD_SPACE          36
+#define NSD_BOS            37
+#define NSD_EOS            38
+#define NSD_PAD            39
+#define NSD_MAX_BEAM       64
+#define NSD_MAX_STEPS      128
+#define NSD_MAX_ORDER      10
+#define NSD_NODE_DEAD      0xFFFFFFFFu
+#define NSD_KEY_EMPTY      0xFFFFFFFFFFFFFFFFull
+#define NSD_TOKEN_CARRY    0xFFu     /* "no token this step": a finished hypothesis carried over */
+
+/* error codes (negative) */
+#define NSD_OK              0
+#define NSD_E_NULL         -1
+#define NSD_E_BEAM         -2   /* beam outside [1, NSD_MAX_BEAM] */
+#define NSD_E_VOCAB        -3   /* V != NSD_V */
+#define NSD_E_ORDER        -4   /* n-gram order outside [0, NSD_MAX_ORDER] */
+#define NSD_E_TABLE        -5   /* malformed table (capacity not a power of two, empty trie, ...) */
+#define NSD_E_VARIANT      -6
+#define NSD_E_SIZE         -7   /* negative / oversized count */
+
+/* beam flags (low byte of NsdBeamState.meta) */
+#define NSD_F_FINISHED      1u  /* last token is EOS */
+#define NSD_F_DEAD          2u  /* left the lexicon: neural top-k fall-back from now on */
+#define NSD_F_PENDING_SPACE 4u  /* surface ends with a space not yet part of the LM sum */
+
+/* per-utterance word NsdBeamState.utt: nbeams | DONE | ERR | nsteps << 16 */
+#define NSD_U_NBEAMS_MASK   0xFFu
+#define NSD_U_DONE          0x100u  /* every hypothesis finished (ns_utils.py:274-275) */
+#define NSD_U_ERR_TOPK      0x200u  /* fall-back asked for k > V in variant I/E (torch.topk raises) */
+#define NSD_U_STEPS_SHIFT   16
+
+/* ---- replicated symbolic tables ------------------------------------ */
+
+/* One trie node.  Replaces the dict-of-dicts Trie (scripts/ns_utils.py:31-56).
+ * Nodes are numbered breadth-first, root = 0; the children of a node are
+ * stored contiguously in ascending token order starting at child_base, so
+ * child(tok) = child_base + popcount(mask & ((1 << tok) - 1)).
+ *   mask bits 0..35 : child exists for that base character
+ *   mask bit  36    : space may follow (is_word, or a literal space edge)
+ *   mask bit  37    : the prefix is a lexicon word (is_word)            */
+typedef struct NsdTrieNode {
+    uint64_t mask;
+    uint32_t child_base;
+    uint32_t reserved;
+} NsdTrieNode;
+
+typedef struct NsdTrieCSR {            /* host memory */
+    const NsdTrieNode *nodes;
+    uint32_t n_nodes;
+} NsdTrieCSR;
+
+/* Open-addressed (linear probing) tables of host-precomputed fp64 log-probs.
+ * Replaces CharNgramLM.counts/.context and the math.log per n-gram of
+ * CharNgramLM.logp (scripts/ns_utils.py:138-150).
+ * Keys pack symbol codes 6 bits each, oldest symbol highest:
+ *   code = token id + 1 for the 37 base characters, 38 for '^', 39 for '$'.
+ * slot index = nsd_hash64(key) & (cap - 1); empty slots hold NSD_KEY_EMPTY. */
+typedef struct NsdGramSlot {           /* key: `order` symbols */
+    uint64_t key;
+    double   logp;                     /* log((c+1)/(C+|V|+1)) */
+} NsdGramSlot;
+
+typedef struct NsdCtxSlot {            /* key: `order-1` symbols */
+    uint64_t key;
+    double   backoff;                  /* log(1/(C+|V|+1)): value of an unseen n-gram in a seen context */
+    double   term;                     /* log((c(ctx+'$')+1)/(C+|V|+1)): the terminal n-gram */
+    uint64_t reserved;
+} NsdCtxSlot;
+
+typedef struct NsdNgramHash {          /* host memory */
+    int32_t  order;                    /* 0 = no language model */
+    int32_t  reserved;
+    uint64_t gram_cap;                 /* power of two */
+    uint64_t ctx_cap;                  /* power of two */
+    const NsdGramSlot *grams;
+    const NsdCtxSlot  *ctxs;
+    double   unseen;                   /* log(1/(|V|+1)): any n-gram in an unseen context */
+} NsdNgramHash;
+
+typedef struct NsdTables NsdTables;    /* opaque, device resident, immutable after create */
+
+/* ---- decode parameters --------------------------------------------- */
+#define NSD_VARIANT_U 0   /* scripts/ns_utils.py:194-278   EOS offered at every step        */
+#define NSD_VARIANT_I 1   /* inference_emg_llm.py:222-300  no EOS option, top-k unclamped   */
+#define NSD_VARIANT_E 2   /* eval_ar.py:214-317            word bonus, boundary EOS, length norm */
+
+typedef struct NsdParams {
+    int32_t variant;
+    int32_t use_lm;                    /* lm is not None */
+    int32_t allow_eos_anytime;         /* ns_utils.py:203 (variant U only) */
+    int32_t min_len_for_eos;           /* eval_ar.py:226 (variant E only) */
+    double  beta;                      /* lm_weight   */
+    double  gamma;                     /* oov_penalty */
+    double  kappa;                     /* word_bonus  (variant E) */
+    double  eos_len_nudge;             /* 0.002, eval_ar.py:293 */
+    /* variant E pruning key = score / len_denom[L], L = generated tokens,
+     * len_denom[L] = ((5+L)**alpha)/(6**alpha) computed by the host
+     * (eval_ar.py:237-241); entry 0 is unused. */
+    double  len_denom[NSD_MAX_STEPS + 4];
+} NsdParams;
+
+/* ---- beam state (structure of device arrays) ------------------------ */
+typedef struct NsdBeamState {
+    double   *score;     /* device [N*B] accumulated raw score (fp64, as the reference's Python floats) */
+    double   *lmsum;     /* device [N*B] running sum of interior n-gram log-probs of the stripped surface */
+    uint64_t *ctx;       /* device [N*B] last order-1 symbols of '^' + stripped surface */
+    uint64_t *hist;      /* device [N*B] rolling hash of the token history (consumed by batched step functions) */
+    uint32_t *node;      /* device [N*B] trie node of the current word prefix, or NSD_NODE_DEAD */
+    uint32_t *meta;      /* device [N*B] flags | generated length << 8 */
+    uint32_t *utt;       /* device [N]   see NSD_U_* */
+    uint32_t *done_count;/* device [1]   number of utterances that reached NSD_U_DONE */
+} NsdBeamState;
+
+/* ---- entry points ---------------------------------------------------- */
+
+int nsd_version(void);
+const char *nsd_strerror(int code);
+
+/* hash used for both tables (exported so that table builders can be checked) */
+uint64_t nsd_hash64(uint64_t key);
+
+/* Upload the tables.  `lm` may be NULL or have order 0 (lm=None).
+ * Replaces build_trie_from_words / CharNgramLM.fit as far as the decoder
+ * reads them (scripts/ns_utils.py:59-65, 99-109). */
+int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm, NsdTables **out);
+int nsd_tables_destroy(NsdTables *t);
+int nsd_tables_order(const NsdTables *t);
+
+/* beams = [(0.0, [BOS], "")] for N utterances (scripts/ns_utils.py:214). */
+int nsd_state_init(const NsdBeamState *st, int32_t N, int32_t B, void *stream);
+
+/* One decode step for N utterances x B beams: the body of the loop at
+ * scripts/ns_utils.py:218-275 (and its copies, see NSD_VARIANT_*).
+ *   logits   device [N*B, V] fp32; row u*B+r is read only if hypothesis r of
+ *            utterance u is live (r < nbeams and not finished)
+ *   in/out   beam state before/after; may be the same object
+ *   backptr  device [N*B] u8: rank of the parent hypothesis   (this step's slice)
+ *   token    device [N*B] u8: appended token or NSD_TOKEN_CARRY (this step's slice)
+ *   mask_dbg device [N*B] u64 or NULL: lexicon mask of each live parent
+ * Utterances already NSD_U_DONE are left untouched. */
+int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
+             const NsdBeamState *in, const NsdBeamState *out,
+             uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,
+             int32_t N, int32_t B, int32_t V, void *stream);
+
+/* Follow the back-pointers of the best hypothesis (rank 0: the first maximal
+ * element, scripts/ns_utils.py:277-278).
+ *   backptr/token device [T, N*B] as written by nsd_step, step-major
+ *   out_ids  device [N, T+1] u8, starts with BOS;  out_len device [N] i32
+ *   out_score device [N] f64 or NULL */
+int nsd_backtrace(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token,
+                  int32_t T, int32_t N, int32_t B,
+                  uint8_t *out_ids, int32_t *out_len, double *out_score, void *stream);
+
+/* Token histories of all current hypotheses, for batched step functions that
+ * need ids (inference_emg_llm.py:427-429 builds them per beam on the host).
+ *   out_ids device [N*B, T+1] u8 (BOS first), out_len device [N*B] i32 (0 = no such hypothesis) */
+int nsd_gather_ids(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token,
+                   int32_t T, int32_t N, int32_t B, uint8_t *out_ids, int32_t *out_len, void *stream);
+
+/* CTC greedy proposal: frame argmax, collapse repeats, drop PAD/BOS/EOS
+ * (inference_emg_llm.py:445-455, eval_ar.py:558-568).
+ *   logits device [N, Tp, V] fp32; out_ids device [N, Tp] u8; out_len device [N] i32 */
+int nsd_ctc_greedy(const float *logits, int32_t N, int32_t Tp, int32_t V,
+                   uint8_t *out_ids, int32_t *out_len, void *stream);
+
+/* CharNgramLM.logp of N strings (scripts/ns_utils.py:138-150), used by the
+ * LM rerank (inference_emg_llm.py:461-464).
+ *   text device [N, stride] u8 base-character ids (0..36), len device [N] i32
+ *   out  device [N] f64 */
+int nsd_lm_logp(const NsdTables *t, const uint8_t *text, const int32_t *len,
+                int32_t N, int32_t stride, double *out, void *stream);
+
+/* Teacher-forced sum of token log-probs (eval_ar.py:574-589):
+ *   out[u] = sum_i log_softmax(logits[u, i, :])[target[u, i]], i < len[u]
+ *   logits device [N, L, V] fp32; target device [N, L] u8; len device [N] i32 */
+int nsd_rerank_gather(const float *logits, const uint8_t *target, const int32_t *len,
+                      int32_t N, int32_t L, int32_t V, double *out, void *stream);
+
+/* Row-wise deterministic fp32 log-softmax, the one nsd_step applies
+ * (F.log_softmax at scripts/ns_utils.py:227).  x, out device [rows, V]. */
+int nsd_log_softmax(const float *x, int32_t rows, int32_t V, float *out, void *stream);
+
+/* Synthetic stand-in for the AR head: integer-hash logits with a planted
+ * target, a function of (utterance seed, step, token-history hash) only.
+ *   targets device [N, stride] i8 planted token ids, target_len device [N] i32
+ *   logits  device [N*B, V] fp32 (rows of live hypotheses are written) */
+int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int64_t utt0,
+                     const int8_t *targets, const int32_t *target_len, int32_t stride,
+                     float margin, float *logits, int32_t N, int32_t B, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSDECODE_H */

@@ -1,0 +1,418 @@
+// Tables, state initialisation, back-trace, CTC greedy, LM string scoring,
+// rerank gather, log-softmax and the synthetic logits generator (gfx950).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "nsd_device.h"
+
+// ---------------------------------------------------------------------
+// version / errors
+// ---------------------------------------------------------------------
+extern "C" int nsd_version(void) { return NSD_VERSION; }
+
+extern "C" const char *nsd_strerror(int code)
+{
+    switch (code) {
+    case NSD_OK:        return "ok";
+    case NSD_E_NULL:    return "null pointer argument";
+    case NSD_E_BEAM:    return "beam width outside [1, 64]";
+    case NSD_E_VOCAB:   return "vocabulary size must be 40";
+    case NSD_E_ORDER:   return "n-gram order outside [0, 10]";
+    case NSD_E_TABLE:   return "malformed table";
+    case NSD_E_VARIANT: return "unknown decoder variant";
+    case NSD_E_SIZE:    return "size argument out of range";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown nsdecode error";
+}
+
+extern "C" uint64_t nsd_hash64(uint64_t key) { return nsd_mix64(key); }
+
+// ---------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------
+static bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+
+extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm, NsdTables **out)
+{
+    if (!trie || !out || !trie->nodes) return NSD_E_NULL;
+    if (trie->n_nodes < 1) return NSD_E_TABLE;
+    const int order = lm ? lm->order : 0;
+    if (order < 0 || order > NSD_MAX_ORDER) return NSD_E_ORDER;
+    if (order > 0) {
+        if (!lm->grams || !lm->ctxs) return NSD_E_NULL;
+        if (!is_pow2(lm->gram_cap) || !is_pow2(lm->ctx_cap)) return NSD_E_TABLE;
+    }
+    // children of every node must stay inside the array
+    for (uint32_t i = 0; i < trie->n_nodes; ++i) {
+        const uint64_t kids = trie->nodes[i].mask & ((1ull << 36) - 1);
+        if (kids && (uint64_t)trie->nodes[i].child_base + (uint64_t)__builtin_popcountll(kids) > trie->n_nodes)
+            return NSD_E_TABLE;
+    }
+    NsdTables *t = new NsdTables();
+    memset(t, 0, sizeof(*t));
+    hipError_t e;
+    const size_t nb = sizeof(NsdTrieNode) * (size_t)trie->n_nodes;
+    if ((e = hipMalloc((void **)&t->nodes, nb)) != hipSuccess) { delete t; return (int)e; }
+    if ((e = hipMemcpy(t->nodes, trie->nodes, nb, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    t->n_nodes = trie->n_nodes;
+    t->order = order;
+    if (order > 0) {
+        const size_t gb = sizeof(NsdGramSlot) * (size_t)lm->gram_cap;
+        const size_t cb = sizeof(NsdCtxSlot) * (size_t)lm->ctx_cap;
+        if ((e = hipMalloc((void **)&t->grams, gb)) != hipSuccess) goto fail;
+        if ((e = hipMemcpy(t->grams, lm->grams, gb, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+        if ((e = hipMalloc((void **)&t->ctxs, cb)) != hipSuccess) goto fail;
+        if ((e = hipMemcpy(t->ctxs, lm->ctxs, cb, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+        t->gram_mask = lm->gram_cap - 1;
+        t->ctx_mask = lm->ctx_cap - 1;
+        t->unseen = lm->unseen;
+        t->ctx_sym_mask = order >= 2 ? ((1ull << (6 * (order - 1))) - 1ull) : 0ull;
+    }
+    *out = t;
+    return NSD_OK;
+fail:
+    if (t->nodes) (void)hipFree(t->nodes);
+    if (t->grams) (void)hipFree(t->grams);
+    if (t->ctxs) (void)hipFree(t->ctxs);
+    delete t;
+    return (int)e;
+}
+
+extern "C" int nsd_tables_destroy(NsdTables *t)
+{
+    if (!t) return NSD_OK;
+    if (t->nodes) (void)hipFree(t->nodes);
+    if (t->grams) (void)hipFree(t->grams);
+    if (t->ctxs) (void)hipFree(t->ctxs);
+    delete t;
+    return NSD_OK;
+}
+
+extern "C" int nsd_tables_order(const NsdTables *t) { return t ? t->order : NSD_E_NULL; }
+
+// ---------------------------------------------------------------------
+// state init
+// ---------------------------------------------------------------------
+__global__ void nsd_state_init_kernel(NsdBeamState st, int N, int B)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u == 0 && st.done_count) *st.done_count = 0;
+    if (u >= N) return;
+    const size_t i = (size_t)u * B;
+    st.score[i] = 0.0;
+    st.lmsum[i] = 0.0;
+    st.ctx[i] = NSD_SYM_HAT;
+    st.hist[i] = NSD_HIST0;
+    st.node[i] = 0;
+    st.meta[i] = 0;
+    st.utt[u] = 1u;            // one hypothesis, not done, zero steps
+}
+
+extern "C" int nsd_state_init(const NsdBeamState *st, int32_t N, int32_t B, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!st || !st->score || !st->lmsum || !st->ctx || !st->hist || !st->node || !st->meta || !st->utt) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_state_init_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *st, N, B);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
+// back-trace
+// ---------------------------------------------------------------------
+// Walks the back-pointers of hypothesis `r0` of utterance u from its last
+// executed step to step 0 and writes BOS + tokens in forward order.
+__device__ int nsd_walk(const uint8_t *backptr, const uint8_t *token, size_t NB, int nsteps,
+                        size_t ubase, int r0, uint8_t *dst /* [T+1] */)
+{
+    // first pass: count tokens
+    int r = r0, n = 0;
+    for (int t = nsteps - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * NB + ubase + r;
+        if (token[o] != NSD_TOKEN_CARRY) ++n;
+        r = backptr[o];
+    }
+    dst[0] = NSD_BOS;
+    r = r0;
+    int k = n;
+    for (int t = nsteps - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * NB + ubase + r;
+        const uint8_t tk = token[o];
+        if (tk != NSD_TOKEN_CARRY) dst[k--] = tk;
+        r = backptr[o];
+    }
+    return n + 1;
+}
+
+__global__ void nsd_backtrace_kernel(NsdBeamState st, const uint8_t *backptr, const uint8_t *token,
+                                     int T, int N, int B, uint8_t *out_ids, int32_t *out_len, double *out_score)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= N) return;
+    const uint32_t um = st.utt[u];
+    int nsteps = (int)(um >> NSD_U_STEPS_SHIFT);
+    if (nsteps > T) nsteps = T;
+    out_len[u] = nsd_walk(backptr, token, (size_t)N * B, nsteps, (size_t)u * B, 0, out_ids + (size_t)u * (T + 1));
+    if (out_score) out_score[u] = st.score[(size_t)u * B];
+}
+
+extern "C" int nsd_backtrace(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token,
+                             int32_t T, int32_t N, int32_t B,
+                             uint8_t *out_ids, int32_t *out_len, double *out_score, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || T < 0 || T > NSD_MAX_STEPS) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!st || !backptr || !token || !out_ids || !out_len) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_backtrace_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       *st, backptr, token, T, N, B, out_ids, out_len, out_score);
+    return (int)hipGetLastError();
+}
+
+__global__ void nsd_gather_ids_kernel(NsdBeamState st, const uint8_t *backptr, const uint8_t *token,
+                                      int T, int N, int B, uint8_t *out_ids, int32_t *out_len)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)N * B) return;
+    const int u = (int)(g / B), r = (int)(g % B);
+    const uint32_t um = st.utt[u];
+    const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
+    int nsteps = (int)(um >> NSD_U_STEPS_SHIFT);
+    if (nsteps > T) nsteps = T;
+    if (r >= nbeams) { out_len[g] = 0; return; }
+    out_len[g] = nsd_walk(backptr, token, (size_t)N * B, nsteps, (size_t)u * B, r, out_ids + (size_t)g * (T + 1));
+}
+
+extern "C" int nsd_gather_ids(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token,
+                              int32_t T, int32_t N, int32_t B, uint8_t *out_ids, int32_t *out_len, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || T < 0 || T > NSD_MAX_STEPS) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!st || !backptr || !token || !out_ids || !out_len) return NSD_E_NULL;
+    const long long tot = (long long)N * B;
+    hipLaunchKernelGGL(nsd_gather_ids_kernel, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       *st, backptr, token, T, N, B, out_ids, out_len);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
+// CTC greedy: one wave per utterance, one lane per frame, 64 frames a round
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nsd_ctc_greedy_kernel(const float *logits, int N, int Tp, uint8_t *out_ids, int32_t *out_len)
+{
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= N) return;
+    const float *base = logits + (size_t)u * Tp * NSD_V;
+    uint8_t *dst = out_ids + (size_t)u * Tp;
+    int prev_tail = -1;          // argmax of the last frame of the previous round
+    int n = 0;
+    for (int t0 = 0; t0 < Tp; t0 += 64) {
+        const int t = t0 + lane;
+        int best = -2;
+        if (t < Tp) {
+            const float4 *row = reinterpret_cast<const float4 *>(base + (size_t)t * NSD_V);
+            float bv = -__builtin_inff();
+            best = 0;
+            bool first = true;
+#pragma unroll
+            for (int q = 0; q < NSD_V / 4; ++q) {
+                const float4 f = row[q];
+                const float v4[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (first || v4[c] > bv) { bv = v4[c]; best = q * 4 + c; first = false; }
+                }
+            }
+        }
+        int prev = __shfl_up(best, 1);
+        if (lane == 0) prev = prev_tail;
+        const bool keep = (t < Tp) && best != prev && best != NSD_PAD && best != NSD_BOS && best != NSD_EOS;
+        const uint64_t bal = __ballot(keep);
+        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (keep) dst[n + (int)pre] = (uint8_t)best;
+        n += __popcll(bal);
+        const int last = (Tp - t0 >= 64) ? 63 : (Tp - t0 - 1);
+        prev_tail = __shfl(best, last);
+    }
+    if (lane == 0) out_len[u] = n;
+}
+
+extern "C" int nsd_ctc_greedy(const float *logits, int32_t N, int32_t Tp, int32_t V,
+                              uint8_t *out_ids, int32_t *out_len, void *stream)
+{
+    if (V != NSD_V) return NSD_E_VOCAB;
+    if (N < 0 || Tp < 0) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!logits || !out_ids || !out_len) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_ctc_greedy_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       logits, N, Tp, out_ids, out_len);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
+// whole-string LM score: sum over the windows of '^' + strip(text) + '$',
+// left to right (the summation order of CharNgramLM.logp)
+// ---------------------------------------------------------------------
+__global__ void nsd_lm_logp_kernel(NsdTables tab, const uint8_t *text, const int32_t *len, int N, int stride, double *out)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= N) return;
+    const uint8_t *s = text + (size_t)u * stride;
+    int a = 0, b = len[u];
+    if (b == 0) { out[u] = -1e9; return; }
+    while (a < b && s[a] == NSD_SPACE) ++a;
+    while (b > a && s[b - 1] == NSD_SPACE) --b;
+    const int order = tab.order;
+    const int n = (b - a) + 2;                 // symbols in '^' + text + '$'
+    double lp = 0.0;
+    uint64_t ctx = 0;                          // last order-1 symbols before the current one
+    for (int i = 0; i < n; ++i) {
+        const uint32_t sym = (i == 0) ? NSD_SYM_HAT : (i == n - 1 ? NSD_SYM_DOLLAR : (uint32_t)s[a + i - 1] + 1u);
+        if (i + 1 >= order) {                  // window ending at symbol i exists
+            double v;
+            if (!nsd_gram_find(tab, (ctx << 6) | sym, v)) v = nsd_ctx_backoff(tab, ctx);
+            lp += v;
+        }
+        ctx = nsd_ctx_shift(tab, ctx, sym);
+    }
+    out[u] = lp;
+}
+
+extern "C" int nsd_lm_logp(const NsdTables *t, const uint8_t *text, const int32_t *len,
+                           int32_t N, int32_t stride, double *out, void *stream)
+{
+    if (!t) return NSD_E_NULL;
+    if (t->order < 1) return NSD_E_ORDER;
+    if (N < 0 || stride < 0) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!text || !len || !out) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_lm_logp_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       *t, text, len, N, stride, out);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
+// log-softmax rows / rerank gather: 8 lanes per row
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nsd_log_softmax_kernel(const float *x, long long rows, float *out)
+{
+    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    float v[5];
+    const bool ok = row < rows;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = ok ? x[row * NSD_V + j * 5 + k] : 0.0f;
+    nsd_row_log_softmax5(v);
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out[row * NSD_V + j * 5 + k] = v[k];
+    }
+}
+
+extern "C" int nsd_log_softmax(const float *x, int32_t rows, int32_t V, float *out, void *stream)
+{
+    if (V != NSD_V) return NSD_E_VOCAB;
+    if (rows < 0) return NSD_E_SIZE;
+    if (rows == 0) return NSD_OK;
+    if (!x || !out) return NSD_E_NULL;
+    const long long threads = (long long)rows * 8;
+    hipLaunchKernelGGL(nsd_log_softmax_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (long long)rows, out);
+    return (int)hipGetLastError();
+}
+
+// 8 lanes per utterance; positions are visited in order so that the fp64 sum
+// is accumulated left to right like the reference's Python loop
+__global__ void __launch_bounds__(256)
+nsd_rerank_gather_kernel(const float *logits, const uint8_t *target, const int32_t *len, int N, int Lmax, double *out)
+{
+    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    const bool ok = u < N;
+    const int n = ok ? len[u] : 0;
+    int nmax = n;
+    nmax = max(nmax, __shfl_xor(nmax, 8));
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    double tot = 0.0;
+    for (int i = 0; i < nmax; ++i) {
+        const bool act = i < n;
+        float v[5];
+        const float *row = logits + ((size_t)(ok ? u : 0) * Lmax + (act ? i : 0)) * NSD_V + j * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = act ? row[k] : 0.0f;
+        nsd_row_log_softmax5(v);
+        const int tg = act ? (int)target[(size_t)u * Lmax + i] : 0;
+        float mine = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mine = (tg == j * 5 + k) ? v[k] : mine;
+        const float val = __shfl(mine, (threadIdx.x & 56) + tg / 5);
+        if (act) tot += (double)val;
+    }
+    if (ok && j == 0) out[u] = tot;
+}
+
+extern "C" int nsd_rerank_gather(const float *logits, const uint8_t *target, const int32_t *len,
+                                 int32_t N, int32_t L, int32_t V, double *out, void *stream)
+{
+    if (V != NSD_V) return NSD_E_VOCAB;
+    if (N < 0 || L < 0) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!logits || !target || !len || !out) return NSD_E_NULL;
+    const long long threads = (long long)N * 8;
+    hipLaunchKernelGGL(nsd_rerank_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, logits, target, len, N, L, out);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
+// synthetic logits: 8 lanes per row, 5 values per lane
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nsd_synth_logits_kernel(NsdBeamState st, uint64_t base_seed, long long utt0, const int8_t *targets,
+                        const int32_t *target_len, int stride, float margin, float *logits, int N, int B)
+{
+    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    if (row >= (long long)N * B) return;
+    const int u = (int)(row / B), r = (int)(row % B);
+    const uint32_t um = st.utt[u];
+    if ((um & NSD_U_DONE) || r >= (int)(um & NSD_U_NBEAMS_MASK)) return;
+    const uint32_t meta = st.meta[row];
+    if (meta & NSD_F_FINISHED) return;
+    const int step = (int)(meta >> 8);
+    const int tgt = step < target_len[u] ? (int)targets[(size_t)u * stride + step] : NSD_EOS;
+    const uint64_t useed = nsd_mix64(base_seed + (uint64_t)(utt0 + u) * 0xD1B54A32D192ED03ull);
+    const uint64_t k = nsd_mix64(st.hist[row] ^ nsd_mix64(useed + (uint64_t)step * NSD_GOLD));
+    const uint32_t rk = (uint32_t)(k ^ (k >> 32));
+    float *dst = logits + row * NSD_V + j * 5;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int v = j * 5 + q;
+        const uint32_t h = nsd_fmix32(rk + (uint32_t)v * 0x9E3779B9u);
+        float x = ((float)(h >> 8) * 5.9604644775390625e-08f - 0.5f) * 4.0f;
+        if (v == tgt) x = x + margin;
+        dst[q] = x;
+    }
+}
+
+extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int64_t utt0,
+                                const int8_t *targets, const int32_t *target_len, int32_t stride,
+                                float margin, float *logits, int32_t N, int32_t B, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || stride < 0) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!st || !targets || !target_len || !logits) return NSD_E_NULL;
+    const long long threads = (long long)N * B * 8;
+    hipLaunchKernelGGL(nsd_synth_logits_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, *st, base_seed, (long long)utt0, targets, target_len, stride,
+                       margin, logits, N, B);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,181 @@
+// Device-side helpers shared by the NS decoder kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nsdecode.h"
+
+struct NsdTables {
+    NsdTrieNode *nodes;
+    uint32_t     n_nodes;
+    int32_t      order;
+    NsdGramSlot *grams;
+    uint64_t     gram_mask;      // cap - 1
+    NsdCtxSlot  *ctxs;
+    uint64_t     ctx_mask;       // cap - 1
+    double       unseen;
+    uint64_t     ctx_sym_mask;   // keeps the last order-1 symbols of a packed context
+};
+
+#define NSD_SYM_HAT    38u
+#define NSD_SYM_DOLLAR 39u
+#define NSD_GOLD  0x9E3779B97F4A7C15ull
+#define NSD_HIST0 0x6A09E667F3BCC908ull
+
+#define NSD_HD __host__ __device__ __forceinline__
+#define NSD_D  __device__ __forceinline__
+
+NSD_HD uint64_t nsd_mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+NSD_HD uint32_t nsd_fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+NSD_HD uint64_t nsd_hist_next(uint64_t h, uint32_t tok)
+{
+    return nsd_mix64(h ^ ((uint64_t)(tok + 1u) * NSD_GOLD));
+}
+
+// ---------------------------------------------------------------------
+// Deterministic fp32 exp / log: individually rounded fp32 operations and
+// fused multiply-adds only, so that a host implementation of the same
+// sequence gives the same bits.  Build with -ffp-contract=off.
+// ---------------------------------------------------------------------
+NSD_D float nsd_det_expf(float d)
+{
+    if (!(d >= -80.0f)) return 0.0f;
+    float k = __builtin_rintf(d * 1.44269504088896341f);
+    float r = __builtin_fmaf(k, -0.693359375f, d);
+    r = __builtin_fmaf(k, 2.12194440e-4f, r);
+    float z = r * r;
+    float y = 1.9875691500e-4f;
+    y = __builtin_fmaf(y, r, 1.3981999507e-3f);
+    y = __builtin_fmaf(y, r, 8.3334519073e-3f);
+    y = __builtin_fmaf(y, r, 4.1665795894e-2f);
+    y = __builtin_fmaf(y, r, 1.6666665459e-1f);
+    y = __builtin_fmaf(y, r, 5.0000001201e-1f);
+    y = __builtin_fmaf(y, z, r);
+    y = y + 1.0f;
+    return __builtin_ldexpf(y, (int)k);
+}
+
+NSD_D float nsd_det_logf(float t)
+{
+    uint32_t bits = __float_as_uint(t);
+    int e = (int)((bits >> 23) & 0xffu) - 126;
+    float f = __uint_as_float((bits & 0x007fffffu) | 0x3f000000u);
+    if (f < 0.707106781186547524f) {
+        e -= 1;
+        f = (f + f) - 1.0f;
+    } else {
+        f = f - 1.0f;
+    }
+    float z = f * f;
+    float y = 7.0376836292e-2f;
+    y = __builtin_fmaf(y, f, -1.1514610310e-1f);
+    y = __builtin_fmaf(y, f, 1.1676998740e-1f);
+    y = __builtin_fmaf(y, f, -1.2420140846e-1f);
+    y = __builtin_fmaf(y, f, 1.4249322787e-1f);
+    y = __builtin_fmaf(y, f, -1.6668057665e-1f);
+    y = __builtin_fmaf(y, f, 2.0000714765e-1f);
+    y = __builtin_fmaf(y, f, -2.4999993993e-1f);
+    y = __builtin_fmaf(y, f, 3.3333331174e-1f);
+    y = y * f;
+    y = y * z;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = f + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// Log-softmax of one 40-wide row spread over 8 consecutive lanes, 5
+// consecutive elements per lane.  Summation tree: each lane sums its 5
+// exponentials left to right, then the 8 partial sums are combined pairwise
+// at lane distance 1, 2, 4 (every lane ends with the same total).
+// x[] is replaced by the log-probabilities.
+NSD_D void nsd_row_log_softmax5(float (&x)[5])
+{
+    float m = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), x[4]);
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4));
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        x[k] = x[k] - m;
+        float e = nsd_det_expf(x[k]);
+        s = (k == 0) ? e : s + e;
+    }
+    s = s + __shfl_xor(s, 1);
+    s = s + __shfl_xor(s, 2);
+    s = s + __shfl_xor(s, 4);
+    float lse = nsd_det_logf(s);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = x[k] - lse;
+}
+
+// ---------------------------------------------------------------------
+// n-gram tables
+// ---------------------------------------------------------------------
+NSD_D bool nsd_gram_find(const NsdTables &t, uint64_t key, double &val)
+{
+    uint64_t h = nsd_mix64(key) & t.gram_mask;
+    for (;;) {
+        const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(&t.grams[h]);
+        if (s.x == key) { val = __longlong_as_double((long long)s.y); return true; }
+        if (s.x == NSD_KEY_EMPTY) return false;
+        h = (h + 1) & t.gram_mask;
+    }
+}
+
+NSD_D const NsdCtxSlot *nsd_ctx_find(const NsdTables &t, uint64_t key)
+{
+    uint64_t h = nsd_mix64(key) & t.ctx_mask;
+    for (;;) {
+        const uint64_t k = t.ctxs[h].key;
+        if (k == key) return &t.ctxs[h];
+        if (k == NSD_KEY_EMPTY) return nullptr;
+        h = (h + 1) & t.ctx_mask;
+    }
+}
+
+NSD_D double nsd_ctx_backoff(const NsdTables &t, uint64_t ctx)
+{
+    const NsdCtxSlot *s = nsd_ctx_find(t, ctx);
+    return s ? s->backoff : t.unseen;
+}
+
+NSD_D double nsd_ctx_term(const NsdTables &t, uint64_t ctx)
+{
+    const NsdCtxSlot *s = nsd_ctx_find(t, ctx);
+    return s ? s->term : t.unseen;
+}
+
+// log-prob of the n-gram (ctx, sym); `backoff` is the value for a seen
+// context whose n-gram is unseen (already looked up by the caller)
+NSD_D double nsd_gram_logp(const NsdTables &t, uint64_t ctx, uint32_t sym, double backoff)
+{
+    double v;
+    return nsd_gram_find(t, (ctx << 6) | sym, v) ? v : backoff;
+}
+
+NSD_D uint64_t nsd_ctx_shift(const NsdTables &t, uint64_t ctx, uint32_t sym)
+{
+    return ((ctx << 6) | sym) & t.ctx_sym_mask;
+}
+
+// compiler + LDS ordering point between lanes of one wave
+NSD_D void nsd_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

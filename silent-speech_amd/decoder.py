@@ -1,0 +1,357 @@
+"""Host side of the MI355X NS decoder.
+
+``constrained_beam_decode`` keeps the reference's signature and call pattern
+(scripts/ns_utils.py:194-204; the in-file copies at
+inference_emg_llm.py:222-231 and eval_ar.py:214-227 are selected with
+``variant``), ``NSDecoder`` is the batched form: N utterances x B beams advance
+in lock step, one ``nsd_step`` launch per step, state and back-pointers
+resident in HBM.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .tables import (BASE_CHARS, BOS_ID, EOS_ID, PAD_ID, VOCAB, HostTrie, NgramTables, compile_ngram,
+                     flatten_trie)
+
+__all__ = ["DeviceTables", "NSDecoder", "Workspace", "constrained_beam_decode", "ids_to_text",
+           "ctc_greedy_batch", "lm_logp_batch", "rerank_gather_batch", "log_softmax_rows"]
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda():
+    if not torch.cuda.is_available():
+        raise _lib.NsdError("the NS decoder runs on an MI355X only: no HIP device is visible "
+                            "(there is no CPU fall-back)")
+
+
+class DeviceTables:
+    """Trie + n-gram tables resident on the current device (immutable)."""
+
+    def __init__(self, nodes: np.ndarray, ngram: Optional[NgramTables]):
+        _require_cuda()
+        L = _lib.load()
+        self.nodes = np.ascontiguousarray(nodes)
+        self.ngram = ngram
+        trie = _lib.TrieCSR(_lib.np_ptr(self.nodes), int(self.nodes.shape[0]))
+        lm = None
+        if ngram is not None:
+            self._g = np.ascontiguousarray(ngram.grams)
+            self._c = np.ascontiguousarray(ngram.ctxs)
+            lm = _lib.NgramHash(ngram.order, 0, self._g.shape[0], self._c.shape[0],
+                                _lib.np_ptr(self._g), _lib.np_ptr(self._c), ngram.unseen)
+        h = C.c_void_p()
+        _lib.check(L.nsd_tables_create(C.byref(trie), C.byref(lm) if lm is not None else None, C.byref(h)),
+                   "nsd_tables_create")
+        self.handle = h
+        self.order = ngram.order if ngram is not None else 0
+
+    @classmethod
+    def from_objects(cls, trie, lm=None, floor_vsz: Optional[bool] = None) -> "DeviceTables":
+        """From reference-style objects: a trie exposing .next/.end and an LM
+        exposing .order/.counts/.context/.V (or None)."""
+        for attr in ("next", "end"):
+            if not hasattr(trie, attr):
+                raise TypeError("trie must expose .next and .end like the reference Trie")
+        ngram = None
+        if lm is not None:
+            for attr in ("order", "counts", "context", "V"):
+                if not hasattr(lm, attr):
+                    raise TypeError("lm must expose order/counts/context/V like CharNgramLM "
+                                    "(KenLM models are not supported)")
+            ngram = compile_ngram(lm, floor_vsz)
+        return cls(flatten_trie(trie), ngram)
+
+    @classmethod
+    def from_words(cls, words: Sequence[str], lm=None, floor_vsz: Optional[bool] = None) -> "DeviceTables":
+        return cls.from_objects(HostTrie.from_words(words), lm, floor_vsz)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().nsd_tables_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Workspace:
+    """Caller-owned device buffers of one batch (N utterances x B beams, T steps)."""
+
+    def __init__(self, N: int, B: int, T: int, device, with_masks: bool = False):
+        self.N, self.B, self.T = N, B, T
+        NB = max(N * B, 1)
+        kw = dict(device=device)
+        self.score = torch.zeros(NB, dtype=torch.float64, **kw)
+        self.lmsum = torch.zeros(NB, dtype=torch.float64, **kw)
+        self.ctx = torch.zeros(NB, dtype=torch.int64, **kw)
+        self.hist = torch.zeros(NB, dtype=torch.int64, **kw)
+        self.node = torch.zeros(NB, dtype=torch.int32, **kw)
+        self.meta = torch.zeros(NB, dtype=torch.int32, **kw)
+        self.utt = torch.zeros(max(N, 1), dtype=torch.int32, **kw)
+        self.done_count = torch.zeros(1, dtype=torch.int32, **kw)
+        self.logits = torch.zeros(max(NB, 1), VOCAB, dtype=torch.float32, **kw)
+        self.backptr = torch.zeros(max(T, 1), max(NB, 1), dtype=torch.uint8, **kw)
+        self.token = torch.zeros(max(T, 1), max(NB, 1), dtype=torch.uint8, **kw)
+        self.masks = torch.zeros(max(T, 1), max(NB, 1), dtype=torch.int64, **kw) if with_masks else None
+        self.out_ids = torch.zeros(max(N, 1), T + 1, dtype=torch.uint8, **kw)
+        self.out_len = torch.zeros(max(N, 1), dtype=torch.int32, **kw)
+        self.out_score = torch.zeros(max(N, 1), dtype=torch.float64, **kw)
+        self.ptrs = _lib.BeamStatePtrs(self.score.data_ptr(), self.lmsum.data_ptr(), self.ctx.data_ptr(),
+                                       self.hist.data_ptr(), self.node.data_ptr(), self.meta.data_ptr(),
+                                       self.utt.data_ptr(), self.done_count.data_ptr())
+        self.steps_run = 0
+
+
+class NSDecoder:
+    """Batched NS beam decoder; parameters as in the reference signatures."""
+
+    def __init__(self, tables: DeviceTables, beam: int, max_new_tokens: int, *, variant: str = "U",
+                 lm_weight: float = 0.3, oov_penalty: float = 1.0, allow_eos_anytime: bool = True,
+                 word_bonus: float = 0.0, length_penalty_alpha: float = 0.6, min_len_for_eos: int = 8,
+                 use_lm: Optional[bool] = None, device=None):
+        _require_cuda()
+        if variant not in _lib.VARIANTS:
+            raise ValueError("variant must be 'U', 'I' or 'E'")
+        if not 1 <= int(beam) <= _lib.MAX_BEAM:
+            raise ValueError(f"beam {beam} outside [1, {_lib.MAX_BEAM}]")
+        if not 0 <= int(max_new_tokens) <= _lib.MAX_STEPS:
+            raise ValueError(f"max_new_tokens {max_new_tokens} outside [0, {_lib.MAX_STEPS}]")
+        self.L = _lib.load()
+        self.tables = tables
+        self.B, self.T, self.variant = int(beam), int(max_new_tokens), variant
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if use_lm is None:
+            use_lm = tables.order > 0
+        self.params = _lib.make_params(variant, use_lm=use_lm and tables.order > 0, beta=lm_weight,
+                                       gamma=oov_penalty, kappa=word_bonus, alpha=length_penalty_alpha,
+                                       min_len_for_eos=min_len_for_eos, allow_eos_anytime=allow_eos_anytime)
+
+    # -- low level ---------------------------------------------------------
+    def workspace(self, N: int, with_masks: bool = False) -> Workspace:
+        return Workspace(int(N), self.B, self.T, self.device, with_masks)
+
+    def init(self, ws: Workspace) -> None:
+        _lib.check(self.L.nsd_state_init(C.byref(ws.ptrs), ws.N, ws.B, _stream_ptr()), "nsd_state_init")
+        ws.steps_run = 0
+
+    def step(self, ws: Workspace, logits: Optional[torch.Tensor] = None) -> None:
+        """One scorer launch on step index ws.steps_run."""
+        t = ws.steps_run
+        if t >= ws.T:
+            raise ValueError("all max_new_tokens steps already ran")
+        lg = ws.logits if logits is None else logits
+        if lg.dtype != torch.float32 or not lg.is_contiguous() or lg.numel() != max(ws.N * ws.B, 1) * VOCAB \
+                or lg.device != ws.score.device:
+            raise ValueError("logits must be a contiguous float32 [N*B, 40] tensor on the decoder's device")
+        NB = max(ws.N * ws.B, 1)
+        mask_ptr = ws.masks.data_ptr() + t * NB * 8 if ws.masks is not None else None
+        _lib.check(self.L.nsd_step(self.tables.handle, C.byref(self.params), lg.data_ptr(),
+                                   C.byref(ws.ptrs), C.byref(ws.ptrs),
+                                   ws.backptr.data_ptr() + t * NB, ws.token.data_ptr() + t * NB, mask_ptr,
+                                   ws.N, ws.B, VOCAB, _stream_ptr()), "nsd_step")
+        ws.steps_run = t + 1
+
+    def all_done(self, ws: Workspace) -> bool:
+        return int(ws.done_count.item()) >= ws.N
+
+    def gather_ids(self, ws: Workspace):
+        """Token histories of all current hypotheses: (ids u8 [N*B, T+1], len i32 [N*B])."""
+        ids = torch.zeros(max(ws.N * ws.B, 1), ws.T + 1, dtype=torch.uint8, device=self.device)
+        lens = torch.zeros(max(ws.N * ws.B, 1), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.nsd_gather_ids(C.byref(ws.ptrs), ws.backptr.data_ptr(), ws.token.data_ptr(),
+                                         ws.T, ws.N, ws.B, ids.data_ptr(), lens.data_ptr(), _stream_ptr()),
+                   "nsd_gather_ids")
+        return ids, lens
+
+    def finish(self, ws: Workspace):
+        """Back-trace the best hypothesis of every utterance; raises like
+        torch.topk when a fall-back needed more candidates than the vocabulary
+        holds (variants I/E)."""
+        _lib.check(self.L.nsd_backtrace(C.byref(ws.ptrs), ws.backptr.data_ptr(), ws.token.data_ptr(),
+                                        ws.T, ws.N, ws.B, ws.out_ids.data_ptr(), ws.out_len.data_ptr(),
+                                        ws.out_score.data_ptr(), _stream_ptr()), "nsd_backtrace")
+        if ws.N and bool((ws.utt[:ws.N] & _lib.U_ERR_TOPK).any().item()):
+            raise RuntimeError("selected index k out of range (beam larger than the vocabulary in the "
+                               "top-k fall-back)")
+        return ws.out_ids[:ws.N], ws.out_len[:ws.N], ws.out_score[:ws.N]
+
+    # -- drivers -----------------------------------------------------------
+    def decode_batch(self, step_fn_batched: Callable, N: int, *, needs_ids: bool = True, check_every: int = 8,
+                     ws: Optional[Workspace] = None):
+        """``step_fn_batched(ids_u8[N*B, T+1], len_i32[N*B], ws) -> float32 logits [N*B, 40]``
+        on the decoder's device (rows of finished / absent hypotheses are ignored)."""
+        ws = ws or self.workspace(N)
+        self.init(ws)
+        for t in range(self.T):
+            ids, lens = self.gather_ids(ws) if needs_ids else (None, None)
+            logits = step_fn_batched(ids, lens, ws)
+            self.step(ws, logits)
+            if check_every and (t + 1) % check_every == 0 and self.all_done(ws):
+                break
+        return self.finish(ws)
+
+    def synth_logits(self, ws: Workspace, base_seed: int, utt0: int, targets: torch.Tensor,
+                     target_len: torch.Tensor, margin: float) -> None:
+        _lib.check(self.L.nsd_synth_logits(C.byref(ws.ptrs), base_seed, utt0, targets.data_ptr(),
+                                           target_len.data_ptr(), targets.shape[1], float(margin),
+                                           ws.logits.data_ptr(), ws.N, ws.B, _stream_ptr()), "nsd_synth_logits")
+
+    def decode_synth(self, targets: torch.Tensor, target_len: torch.Tensor, *, base_seed: int, margin: float,
+                     utt0: int = 0, check_every: int = 8, ws: Optional[Workspace] = None):
+        """Decode with the synthetic integer-hash AR head (int8 targets [N, S] on device)."""
+        N = targets.shape[0]
+        ws = ws or self.workspace(N)
+        self.init(ws)
+        for t in range(self.T):
+            self.synth_logits(ws, base_seed, utt0, targets, target_len, margin)
+            self.step(ws)
+            if check_every and (t + 1) % check_every == 0 and self.all_done(ws):
+                break
+        return self.finish(ws)
+
+
+# ----------------------------------------------------------------------
+# drop-in for the reference function
+# ----------------------------------------------------------------------
+_TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def _tables_for(trie, lm, floor_vsz) -> DeviceTables:
+    key = (id(trie), id(lm), floor_vsz, torch.cuda.current_device())
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None and hit[0] is trie and hit[1] is lm:
+        _TABLE_CACHE.move_to_end(key)
+        return hit[2]
+    t = DeviceTables.from_objects(trie, lm, floor_vsz)
+    _TABLE_CACHE[key] = (trie, lm, t)
+    while len(_TABLE_CACHE) > 4:
+        _TABLE_CACHE.popitem(last=False)
+    return t
+
+
+def _check_tt(TT) -> None:
+    TT.BASE_CHARS.index(" ")           # ValueError without a space, as the reference (ns_utils.py:215)
+    if (TT.BASE_CHARS != BASE_CHARS or TT.VOCAB_OFFSET != 0 or TT.BOS_IDX != BOS_ID or TT.EOS_IDX != EOS_ID
+            or TT.PAD_IDX != PAD_ID or TT.VOCAB_SIZE != VOCAB):
+        raise NotImplementedError("the HIP decoder implements the reference TextTransform layout only "
+                                  "(a-z0-9 + space, BOS=37, EOS=38, PAD=39, offset 0)")
+
+
+def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, lm=None,
+                            lm_weight: float = 0.3, oov_penalty: float = 1.0, allow_eos_anytime: bool = True,
+                            *, variant: str = "U", word_bonus: float = 0.0,
+                            length_penalty_alpha: float = 0.6, min_len_for_eos: int = 8) -> List[int]:
+    """Drop-in for the reference's single-utterance decoder.
+
+    ``step_fn(ids: List[int]) -> Tensor[1, V]`` is called once per live
+    hypothesis per step, in rank order, exactly as the reference calls it;
+    everything between those calls (log-softmax, lexicon mask, LM fusion,
+    pruning) runs in one nsd_step launch.  variant "U" = scripts/ns_utils.py,
+    "I" = inference_emg_llm.py, "E" = eval_ar.py (keyword-only extras).
+    """
+    _require_cuda()
+    _check_tt(TT)
+    tables = _tables_for(trie, lm, None)
+    dec = NSDecoder(tables, beam, max_new_tokens, variant=variant, lm_weight=lm_weight,
+                    oov_penalty=oov_penalty, allow_eos_anytime=allow_eos_anytime, word_bonus=word_bonus,
+                    length_penalty_alpha=length_penalty_alpha, min_len_for_eos=min_len_for_eos,
+                    use_lm=lm is not None)
+    B = dec.B
+    ws = dec.workspace(1)
+    dec.init(ws)
+    hyps: List[List[int]] = [[BOS_ID]]
+    for t in range(dec.T):
+        rows = torch.zeros(B, VOCAB, dtype=torch.float32)
+        dev_rows = []
+        for r, ids in enumerate(hyps):
+            if ids[-1] == EOS_ID:
+                continue
+            out = step_fn(list(ids))
+            dev_rows.append((r, out.detach().reshape(-1).to(dtype=torch.float32)))
+        logits = rows.to(dec.device)
+        for r, v in dev_rows:
+            logits[r] = v.to(dec.device)
+        dec.step(ws, logits)
+        um = int(ws.utt[0].item())
+        if um & _lib.U_ERR_TOPK:
+            raise RuntimeError("selected index k out of range")
+        nb = um & 0xFF
+        par = ws.backptr[t, :nb].tolist()
+        tok = ws.token[t, :nb].tolist()
+        hyps = [hyps[p] if k == _lib.TOKEN_CARRY else hyps[p] + [k] for p, k in zip(par, tok)]
+        if um & _lib.U_DONE:
+            break
+    return hyps[0]
+
+
+def ids_to_text(TT, ids: Sequence[int]) -> str:
+    """scripts/ns_utils.py:284-296."""
+    out = []
+    for i in ids[1:]:
+        if i == TT.EOS_IDX:
+            break
+        j = i - TT.VOCAB_OFFSET
+        if 0 <= j < len(TT.BASE_CHARS):
+            out.append(TT.BASE_CHARS[j])
+    return "".join(out).strip()
+
+
+# ----------------------------------------------------------------------
+# CTC proposal and rerank pieces
+# ----------------------------------------------------------------------
+def ctc_greedy_batch(logits: torch.Tensor):
+    """(N, T', 40) float32 device logits -> (ids u8 [N, T'], len i32 [N])
+    (inference_emg_llm.py:445-455)."""
+    _require_cuda()
+    N, Tp, V = logits.shape
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise ValueError("logits must be contiguous float32")
+    ids = torch.zeros(max(N, 1), max(Tp, 1), dtype=torch.uint8, device=logits.device)
+    lens = torch.zeros(max(N, 1), dtype=torch.int32, device=logits.device)
+    _lib.check(_lib.load().nsd_ctc_greedy(logits.data_ptr(), N, Tp, V, ids.data_ptr(), lens.data_ptr(),
+                                          _stream_ptr()), "nsd_ctc_greedy")
+    return ids[:N], lens[:N]
+
+
+def lm_logp_batch(tables: DeviceTables, text_ids: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+    """CharNgramLM.logp of N strings given as base-character ids u8 [N, S]."""
+    _require_cuda()
+    N, S = text_ids.shape
+    out = torch.zeros(max(N, 1), dtype=torch.float64, device=text_ids.device)
+    _lib.check(_lib.load().nsd_lm_logp(tables.handle, text_ids.data_ptr(), lens.data_ptr(), N, S,
+                                       out.data_ptr(), _stream_ptr()), "nsd_lm_logp")
+    return out[:N]
+
+
+def rerank_gather_batch(logits: torch.Tensor, target: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+    """Teacher-forced sum of token log-probs (eval_ar.py:574-589):
+    logits float32 [N, L, 40], target u8 [N, L], lens i32 [N] -> f64 [N]."""
+    _require_cuda()
+    N, Lm, V = logits.shape
+    out = torch.zeros(max(N, 1), dtype=torch.float64, device=logits.device)
+    _lib.check(_lib.load().nsd_rerank_gather(logits.data_ptr(), target.data_ptr(), lens.data_ptr(), N, Lm, V,
+                                             out.data_ptr(), _stream_ptr()), "nsd_rerank_gather")
+    return out[:N]
+
+
+def log_softmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """The decoder's deterministic fp32 log-softmax over the last dim (=40)."""
+    _require_cuda()
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().nsd_log_softmax(x.data_ptr(), rows, x.shape[-1], out.data_ptr(), _stream_ptr()),
+               "nsd_log_softmax")
+    return out

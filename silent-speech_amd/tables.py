@@ -1,0 +1,267 @@
+"""Table compiler: lexicon trie and char n-gram counts -> flat device tables.
+
+Host-side replacement for the reference's dict-of-dicts ``Trie``
+(scripts/ns_utils.py:31-65) and ``CharNgramLM`` dictionaries
+(scripts/ns_utils.py:86-150): the trie becomes an array of 16-byte node
+records numbered breadth-first, the n-gram counts become two open-addressed
+hash tables of fp64 log-probabilities computed here with ``math.log`` exactly
+as ``CharNgramLM.logp`` computes them, so the device only adds.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+BASE_CHARS = "abcdefghijklmnopqrstuvwxyz0123456789 "
+SPACE_ID = 36
+BOS_ID, EOS_ID, PAD_ID, VOCAB = 37, 38, 39, 40
+MAX_ORDER = 10
+KEY_EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+NODE_DTYPE = np.dtype([("mask", "<u8"), ("child_base", "<u4"), ("reserved", "<u4")])
+GRAM_DTYPE = np.dtype([("key", "<u8"), ("logp", "<f8")])
+CTX_DTYPE = np.dtype([("key", "<u8"), ("backoff", "<f8"), ("term", "<f8"), ("reserved", "<u8")])
+
+_CHILD_CHARS = BASE_CHARS[:36]
+_TOK = {c: i for i, c in enumerate(BASE_CHARS)}
+SYM = {c: i + 1 for i, c in enumerate(BASE_CHARS)}
+SYM["^"] = 38
+SYM["$"] = 39
+
+
+class HostTrie:
+    """Minimal dict trie with the reference's duck type (.next, .end)."""
+
+    __slots__ = ("next", "end")
+
+    def __init__(self):
+        self.next = {}
+        self.end = False
+
+    @classmethod
+    def from_words(cls, words: Iterable[str]) -> "HostTrie":
+        """Words are stripped and lower-cased, empties dropped
+        (build_trie_from_words, scripts/ns_utils.py:59-65)."""
+        root = cls()
+        for w in words:
+            w = (w or "").strip().lower()
+            if not w:
+                continue
+            node = root
+            for ch in w:
+                nxt = node.next.get(ch)
+                if nxt is None:
+                    nxt = node.next[ch] = cls()
+                node = nxt
+            node.end = True
+        return root
+
+
+def load_lexicon_words(path: str, extra: Optional[str] = None) -> list[str]:
+    """Lexicon + optional phrasebook lines, stripped, lower-cased, unique, sorted
+    (load_lexicon, scripts/ns_utils.py:68-80)."""
+    from pathlib import Path
+    words: list[str] = []
+    for p in (path, extra):
+        if p and Path(p).exists():
+            words += [l.strip().lower() for l in Path(p).read_text(encoding="utf-8").splitlines() if l.strip()]
+    return sorted(set(words))
+
+
+def flatten_trie(trie) -> np.ndarray:
+    """Breadth-first array of node records from any object tree exposing
+    ``.next`` (dict char -> node) and ``.end``.
+
+    Only edges labelled with one of the 36 non-space base characters become
+    nodes: an edge with any other label can never be taken by the decoder
+    (scripts/ns_utils.py:246-247), and after a space the decoder restarts
+    from the root (scripts/ns_utils.py:235), so a literal space edge only
+    sets the "space may follow" bit.
+    """
+    order = [trie]
+    masks: list[int] = []
+    bases: list[int] = []
+    i = 0
+    while i < len(order):
+        nd = order[i]
+        kids = sorted((_TOK[c], ch) for c, ch in nd.next.items() if c in _CHILD_CHARS and len(c) == 1)
+        mask = 0
+        for tok, _ in kids:
+            mask |= 1 << tok
+        if nd.end or " " in nd.next:
+            mask |= 1 << SPACE_ID
+        if nd.end:
+            mask |= 1 << 37
+        masks.append(mask)
+        bases.append(len(order))
+        order.extend(ch for _, ch in kids)
+        i += 1
+    out = np.zeros(len(order), dtype=NODE_DTYPE)
+    out["mask"] = np.array(masks, dtype=np.uint64)
+    out["child_base"] = np.array(bases, dtype=np.uint32)
+    return out
+
+
+def mix64(z: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser (the slot hash, nsd_hash64)."""
+    z = z.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def pack_key(s: str) -> Optional[int]:
+    k = 0
+    for ch in s:
+        c = SYM.get(ch)
+        if c is None:
+            return None
+        k = (k << 6) | c
+    return k
+
+
+def _capacity(n: int) -> int:
+    cap = 16
+    while cap < 2 * n:
+        cap *= 2
+    return cap
+
+
+def _place(keys: np.ndarray, cap: int) -> np.ndarray:
+    """Linear-probing slot of every (distinct) key."""
+    n = keys.shape[0]
+    slot = np.full(n, -1, dtype=np.int64)
+    used = np.zeros(cap, dtype=bool)
+    pos = (mix64(keys) & np.uint64(cap - 1)).astype(np.int64)
+    pending = np.arange(n)
+    while pending.size:
+        p = pos[pending]
+        free = ~used[p]
+        cand, pc = pending[free], p[free]
+        _, first = np.unique(pc, return_index=True)
+        win = cand[first]
+        slot[win] = pos[win]
+        used[pos[win]] = True
+        lost = np.ones(pending.size, dtype=bool)
+        lost[np.flatnonzero(free)[first]] = False
+        pending = pending[lost]
+        pos[pending] = (pos[pending] + 1) & (cap - 1)
+    return slot
+
+
+class NgramTables:
+    """Flat hash tables of one CharNgramLM-like object."""
+
+    def __init__(self, order: int, grams: np.ndarray, ctxs: np.ndarray, unseen: float, vsz: int):
+        self.order, self.grams, self.ctxs, self.unseen, self.vsz = order, grams, ctxs, unseen, vsz
+
+
+def compile_ngram(lm, floor_vsz: Optional[bool] = None) -> NgramTables:
+    """``lm`` exposes ``order``, ``counts`` (n-gram -> count), ``context``
+    ((n-1)-gram -> count) and ``V`` (set of characters), as CharNgramLM does.
+
+    ``floor_vsz`` selects the smoothing vocabulary: max(1, |V|)
+    (scripts/ns_utils.py:148) or |V| (inference_emg_llm.py:158,
+    eval_ar.py:162).  When None it is read from ``lm.floor_vsz`` or, for an
+    empty V (the only case where the two differ), probed from ``lm.logp``.
+    """
+    order = int(lm.order)
+    if not 1 <= order <= MAX_ORDER:
+        raise ValueError(f"n-gram order {order} outside [1, {MAX_ORDER}]")
+    nV = len(lm.V)
+    if floor_vsz is None:
+        floor_vsz = getattr(lm, "floor_vsz", None)
+    if floor_vsz is None:
+        floor_vsz = True if nV else bool(float(lm.logp("a" * max(order, 1))) < 0.0)
+    vsz = max(1, nV) if floor_vsz else nV
+    log = math.log
+    context = lm.context
+    counts = lm.counts
+
+    gk, gv = [], []
+    for g, c in counts.items():
+        k = pack_key(g) if len(g) == order else None
+        if k is None:
+            continue
+        gk.append(k)
+        gv.append(log((c + 1) / (context.get(g[:-1], 0) + vsz + 1)))
+    ck, cb, ct = [], [], []
+    for ctx, C in context.items():
+        k = pack_key(ctx) if len(ctx) == order - 1 else None
+        if k is None:
+            continue
+        ck.append(k)
+        cb.append(log((0 + 1) / (C + vsz + 1)))
+        ct.append(log((counts.get(ctx + "$", 0) + 1) / (C + vsz + 1)))
+
+    grams = np.zeros(_capacity(len(gk)), dtype=GRAM_DTYPE)
+    grams["key"] = KEY_EMPTY
+    if gk:
+        keys = np.array(gk, dtype=np.uint64)
+        s = _place(keys, grams.shape[0])
+        grams["key"][s] = keys
+        grams["logp"][s] = np.array(gv, dtype=np.float64)
+    ctxs = np.zeros(_capacity(len(ck)), dtype=CTX_DTYPE)
+    ctxs["key"] = KEY_EMPTY
+    if ck:
+        keys = np.array(ck, dtype=np.uint64)
+        s = _place(keys, ctxs.shape[0])
+        ctxs["key"][s] = keys
+        ctxs["backoff"][s] = np.array(cb, dtype=np.float64)
+        ctxs["term"][s] = np.array(ct, dtype=np.float64)
+    return NgramTables(order, grams, ctxs, log((0 + 1) / (0 + vsz + 1)), vsz)
+
+
+# ----------------------------------------------------------------------
+# host-side lookups over the flat tables (used by the CPU-only tests of the
+# table compiler; the decoder itself only reads them on the device)
+# ----------------------------------------------------------------------
+def host_find(table: np.ndarray, key: int) -> int:
+    cap = table.shape[0]
+    h = int(mix64(np.array([key], dtype=np.uint64))[0]) & (cap - 1)
+    keys = table["key"]
+    while True:
+        k = int(keys[h])
+        if k == key:
+            return h
+        if k == int(KEY_EMPTY):
+            return -1
+        h = (h + 1) & (cap - 1)
+
+
+def host_logp(t: NgramTables, text: str) -> float:
+    """Whole-string score from the flat tables, same summation order as
+    CharNgramLM.logp (scripts/ns_utils.py:138-150)."""
+    if not text:
+        return -1e9
+    s = "^" + text.strip().lower() + "$"
+    n = t.order
+    total = 0.0
+    for i in range(len(s) - n + 1):
+        g = s[i:i + n]
+        gk, ck = pack_key(g), pack_key(g[:-1])
+        v = None
+        if gk is not None:
+            j = host_find(t.grams, gk)
+            if j >= 0:
+                v = float(t.grams["logp"][j])
+        if v is None:
+            j = host_find(t.ctxs, ck) if ck is not None else -1
+            v = float(t.ctxs["backoff"][j]) if j >= 0 else t.unseen
+        total += v
+    return total
+
+
+def host_trie_walk(nodes: np.ndarray, word: str) -> int:
+    """Node index of ``word`` (base characters only) or -1."""
+    cur = 0
+    for ch in word:
+        tok = _TOK.get(ch, 99)
+        mask = int(nodes["mask"][cur])
+        if tok >= 36 or not (mask >> tok) & 1:
+            return -1
+        cur = int(nodes["child_base"][cur]) + bin(mask & ((1 << tok) - 1)).count("1")
+    return cur

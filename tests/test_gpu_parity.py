@@ -1,0 +1,321 @@
+"""GPU parity: the HIP path (through the C ABI of libnsdecode.so) against the
+CPU checkers and the golden vectors recorded from the reference.
+
+Bars: trie masks, beam indices (parents/tokens/live histories), ids and
+transcripts bit-exact; fp64 scores bit-exact against the checker that uses the
+same deterministic log-softmax (and therefore within the 1e-5 relative
+tolerance the task states against the reference's torch log-softmax)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbind, synth
+from oracle import ns_oracle as O
+from tests.golden_util import (case_corpus, case_model, case_targets, case_words, decode_kwargs, enc,
+                               target_tokens)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _pack_targets(targets):
+    toks = [target_tokens(t) for t in targets]
+    S = max(1, max(len(t) for t in toks))
+    tg = np.zeros((len(toks), S), np.int8)
+    for i, t in enumerate(toks):
+        tg[i, :len(t)] = t
+    return tg, np.array([len(t) for t in toks], np.int32)
+
+
+def test_log_softmax_bit_exact(dev):
+    from silent_speech_amd.decoder import log_softmax_rows
+    rng = np.random.RandomState(0)
+    x = np.concatenate([(rng.randn(20000, 40) * s).astype(np.float32) for s in (0.3, 3.0, 30.0, 300.0)])
+    x[::5, 7] += 60.0
+    x[1] = 0.0
+    x[2] = -1e30; x[2, 9] = 1e30
+    got = log_softmax_rows(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = cbind.log_softmax_rows(x)
+    assert got.tobytes() == want.tobytes()
+    ref = torch.log_softmax(torch.from_numpy(x).double(), -1).numpy()
+    assert (np.abs(got - ref) <= 3e-7 * np.maximum(1.0, np.abs(ref))).all()
+
+
+def test_golden_cases_through_the_drop_in(golden, dev):
+    """Every recorded reference run, replayed through the reference-signature
+    entry point: same step_fn call sequence (= live beams in rank order at every
+    step), same lexicon masks, same ids and transcript."""
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.decoder import constrained_beam_decode, ids_to_text
+    code = golden["meta"]["token_code"]
+    n = 0
+    for case in golden["cases"]:
+        words, trie, lm = case_model(case)
+        for u, rec in enumerate(case["utts"]):
+            useed = synth.utt_seed(case["base_seed"], u)
+            tgt = target_tokens(rec["target"])
+            calls = []
+
+            def step_fn(ids):
+                calls.append(enc(ids, code))
+                return torch.from_numpy(synth.logits_row(useed, ids, tgt, case["margin"])).unsqueeze(0)
+
+            kw = decode_kwargs(case)
+            if "raises" in rec:
+                with pytest.raises(RuntimeError):
+                    constrained_beam_decode(step_fn, TextTransform, case["beam"], case["max_new_tokens"], trie, lm, **kw)
+                assert calls == rec["calls"]
+                continue
+            ids = constrained_beam_decode(step_fn, TextTransform, case["beam"], case["max_new_tokens"], trie, lm, **kw)
+            assert calls == rec["calls"], (case["name"], u)
+            assert ids == rec["ids"], (case["name"], u)
+            assert ids_to_text(TextTransform, ids) == rec["text"]
+            n += 1
+    assert n > 80
+
+
+def _run_case_batched(case, dev, with_masks=True):
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    words = case_words(case)
+    corpus = case_corpus(case, words)
+    floor = case["variant"] == "U"
+    lm = O.NgramLM(case["lm_order"], floor_vsz=floor).fit(corpus) if case["lm_order"] > 0 else None
+    targets = case_targets(case, words)
+    tg, tl = _pack_targets(targets)
+    tables = DeviceTables.from_words(words, lm)
+    dec = NSDecoder(tables, case["beam"], case["max_new_tokens"], variant=case["variant"], lm_weight=case["beta"],
+                    oov_penalty=case["gamma"], word_bonus=case["kappa"], length_penalty_alpha=case["alpha"],
+                    min_len_for_eos=case["min_len_for_eos"])
+    ws = dec.workspace(len(targets), with_masks=with_masks)
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    err = None
+    try:
+        ids, lens, scores = dec.decode_synth(tgd, tld, base_seed=case["base_seed"], margin=case["margin"], ws=ws,
+                                             check_every=1)
+    except RuntimeError as e:
+        err = e
+        ids = lens = scores = None
+    cm = cbind.Model(words, corpus, case["lm_order"], floor)
+    ref = cm.decode_synth(variant=case["variant"], beam=case["beam"], max_new_tokens=case["max_new_tokens"],
+                          beta=case["beta"], gamma=case["gamma"], kappa=case["kappa"], alpha=case["alpha"],
+                          min_len_for_eos=case["min_len_for_eos"], margin=case["margin"],
+                          base_seed=case["base_seed"], targets=tg, target_lens=tl, trace=True)
+    return ws, ids, lens, scores, ref, err
+
+
+def _compare_with_trace(ws, ids, lens, scores, ref, name):
+    N, B, T = ws.N, ws.B, ws.T
+    ids, lens, scores = ids.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+    bp = ws.backptr.cpu().numpy().reshape(max(T, 1), N, B)
+    tk = ws.token.cpu().numpy().reshape(max(T, 1), N, B)
+    utt = ws.utt.cpu().numpy()
+    masks = ws.masks.cpu().numpy().reshape(max(T, 1), N, B).view(np.uint64) if ws.masks is not None else None
+    assert (lens == ref["lens"]).all(), name
+    for u in range(N):
+        assert (ids[u, :lens[u]] == ref["ids"][u, :lens[u]]).all(), (name, u)
+        assert float(scores[u]).hex() == float(ref["scores"][u]).hex(), (name, u)
+        steps = int(utt[u]) >> 16
+        assert steps == ref["steps"][u], (name, u)
+        for t in range(steps):
+            nb = ref["nbeams"][u, t]
+            want_tok = ref["token"][u, t, :nb].astype(np.int16)
+            got_tok = tk[t, u, :nb].astype(np.int16)
+            got_tok[got_tok == 0xFF] = -1
+            assert (bp[t, u, :nb] == ref["parent"][u, t, :nb]).all(), (name, u, t)
+            assert (got_tok == want_tok).all(), (name, u, t)
+            if masks is not None:
+                nprev = 1 if t == 0 else ref["nbeams"][u, t - 1]
+                assert (masks[t, u, :nprev] == ref["mask"][u, t, :nprev]).all(), (name, u, t)
+
+
+def test_golden_cases_batched_against_c_checker(golden, dev):
+    """All utterances of a case in one batch with the device-side synthetic AR
+    head; parents, tokens, masks per step and fp64 scores against the C checker."""
+    for case in golden["cases"]:
+        if any(ord(ch) > 127 for w in case.get("extra_words", []) for ch in w):
+            continue
+        ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)
+        if err is not None:
+            assert (ref["lens"] == -1).any(), case["name"]
+            continue
+        _compare_with_trace(ws, ids, lens, scores, ref, case["name"])
+        # final ids equal the reference's own recorded output
+        for u, rec in enumerate(case["utts"]):
+            if "ids" in rec:
+                assert list(ids[u, :int(lens[u])].cpu().numpy()) == rec["ids"], (case["name"], u)
+
+
+@pytest.mark.parametrize("variant,beam,order,beta,margin", [
+    ("U", 16, 5, 0.05, 60.0), ("I", 16, 5, 0.05, 60.0), ("E", 16, 5, 0.05, 60.0),
+    ("U", 32, 5, 0.05, 8.0), ("I", 8, 3, 0.3, 6.0), ("E", 32, 5, 0.1, 10.0), ("U", 2, 2, 0.2, 5.0),
+    ("I", 64, 5, 0.05, 5.0),
+])
+def test_batch_512_against_c_checker(dev, variant, beam, order, beta, margin):
+    case = dict(variant=variant, beam=beam, lm_order=order, beta=beta, margin=margin, gamma=1.0, kappa=0.35,
+                alpha=0.6, min_len_for_eos=8, max_new_tokens=64 if beam <= 16 else 40, n_words=200, lex_seed=0,
+                max_len=8, n_corpus=4000, corpus_seed=1, n_utts=512 if beam <= 32 else 64, target_seed=2,
+                base_seed=99, min_words=3, max_words=7, name=f"b512_{variant}_{beam}")
+    if variant != "U" and beam > 40:
+        case["beam"] = 40
+    ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)
+    assert err is None
+    _compare_with_trace(ws, ids, lens, scores, ref, case["name"])
+
+
+def test_open_lexicon_with_dead_beams(dev):
+    """100k-word lexicon over a-z0-9 plus apostrophe words whose prefix node has
+    no usable child: exercises random-access trie reads and the fall-back."""
+    words = synth.make_lexicon(100000, 1, synth.BASE_CHARS[:36], 2, 12) + ["don't", "can't", "it's"]
+    case = dict(variant="U", beam=32, lm_order=5, beta=0.05, margin=9.0, gamma=1.0, kappa=0.35, alpha=0.6,
+                min_len_for_eos=8, max_new_tokens=24, n_words=0, lex_seed=0, n_corpus=0, corpus_seed=0,
+                n_utts=0, target_seed=0, base_seed=5, name="open100k")
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    plain = [w for w in words if "'" not in w]
+    corpus = synth.make_sentences(plain, 3000, 4)
+    targets = synth.make_sentences(plain, 192, 6, 2, 4) + ["don tx it s", "can t do", "it sx"] * 8
+    tg, tl = _pack_targets(targets)
+    for variant in ("U", "I", "E"):
+        floor = variant == "U"
+        lm = O.NgramLM(5, floor_vsz=floor).fit(corpus)
+        tables = DeviceTables.from_words(words, lm)
+        dec = NSDecoder(tables, 32, 24, variant=variant, lm_weight=0.05, oov_penalty=1.0, word_bonus=0.35)
+        ws = dec.workspace(len(targets), with_masks=True)
+        ids, lens, scores = dec.decode_synth(torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev),
+                                             base_seed=5, margin=9.0, ws=ws, check_every=4)
+        ref = cbind.Model(words, corpus, 5, floor).decode_synth(
+            variant=variant, beam=32, max_new_tokens=24, beta=0.05, gamma=1.0, kappa=0.35, margin=9.0,
+            base_seed=5, targets=tg, target_lens=tl, trace=True)
+        _compare_with_trace(ws, ids, lens, scores, ref, f"open100k_{variant}")
+        meta = ws.meta.cpu().numpy()
+        assert ((meta & 2) != 0).any(), "expected some dead hypotheses in this workload"
+
+
+def test_edge_shapes(dev):
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    tables = DeviceTables.from_words(["ab", "abc", "b"], O.NgramLM(3).fit(["ab abc b"]))
+    # zero utterances, zero steps
+    dec = NSDecoder(tables, 4, 8)
+    ids, lens, _ = dec.decode_synth(torch.zeros(0, 1, dtype=torch.int8, device=dev),
+                                    torch.zeros(0, dtype=torch.int32, device=dev), base_seed=1, margin=5.0)
+    assert ids.shape[0] == 0 and lens.shape[0] == 0
+    dec0 = NSDecoder(tables, 4, 0)
+    ids, lens, _ = dec0.decode_synth(torch.zeros(3, 1, dtype=torch.int8, device=dev),
+                                     torch.zeros(3, dtype=torch.int32, device=dev), base_seed=1, margin=5.0)
+    assert lens.tolist() == [1, 1, 1] and ids[:, 0].tolist() == [37, 37, 37]
+    # maximum steps and beam, ragged targets (empty target included)
+    dec = NSDecoder(tables, 64, 128, variant="U", lm_weight=0.01)
+    tg = np.zeros((5, 40), np.int8); tl = np.array([0, 1, 7, 40, 3], np.int32)
+    tg[:] = np.tile(np.array([0, 1, 36, 1, 36, 0, 1, 2, 36, 1], np.int8), 4)
+    ws = dec.workspace(5, with_masks=True)
+    ids, lens, scores = dec.decode_synth(torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev),
+                                         base_seed=3, margin=40.0, ws=ws)
+    ref = cbind.Model(["ab", "abc", "b"], ["ab abc b"], 3, True).decode_synth(
+        variant="U", beam=64, max_new_tokens=128, beta=0.01, gamma=1.0, margin=40.0, base_seed=3,
+        targets=tg, target_lens=tl, trace=True)
+    _compare_with_trace(ws, ids, lens, scores, ref, "edge")
+    with pytest.raises(ValueError):
+        NSDecoder(tables, 65, 8)
+    with pytest.raises(ValueError):
+        NSDecoder(tables, 4, 129)
+
+
+def test_ctc_greedy(dev):
+    from silent_speech_amd.decoder import ctc_greedy_batch
+    rng = np.random.RandomState(2)
+    N, Tp = 37, 256
+    x = rng.randn(N, Tp, 40).astype(np.float32)
+    # planted frame-repeated targets with blanks (PAD is the CTC blank)
+    for u in range(N):
+        t = 0
+        while t < Tp:
+            tok = int(rng.choice([rng.randint(0, 37), 39, 39, 37, 38]))
+            run = int(rng.randint(1, 6))
+            x[u, t:t + run, tok] += 6.0
+            t += run
+    x[3] = 0.0                                     # all-ties rows: first index wins
+    ids, lens = ctc_greedy_batch(torch.from_numpy(x).to(dev))
+    ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+    for u in range(N):
+        want = O.ctc_greedy(x[u], O.TextTransformLike)
+        assert list(ids[u, :lens[u]]) == want, u
+    # ragged T' that is not a multiple of 64, and the known answers of the collapse rule
+    for Tp in (1, 63, 65, 130):
+        y = rng.randn(5, Tp, 40).astype(np.float32)
+        ids, lens = ctc_greedy_batch(torch.from_numpy(y).to(dev))
+        for u in range(5):
+            assert list(ids[u, :int(lens[u])].cpu().numpy()) == cbind.ctc_greedy(y[u])
+    z = np.full((1, 3, 40), -5.0, np.float32); z[0, 0, 0] = z[0, 1, 39] = z[0, 2, 0] = 3.0
+    ids, lens = ctc_greedy_batch(torch.from_numpy(z).to(dev))
+    assert list(ids[0, :int(lens[0])].cpu().numpy()) == [0, 0]
+
+
+def test_lm_logp_and_rerank(dev):
+    from silent_speech_amd.decoder import DeviceTables, lm_logp_batch, rerank_gather_batch
+    words = synth.make_lexicon(60, 11, max_len=6)
+    corpus = synth.make_sentences(words, 300, 5)
+    texts = ["", " ", "a", "ab", "a ", "abc", "abcd", "ab cd ", " ab", "zz9 q"] + corpus[:40]
+    S = max(len(t) for t in texts)
+    for order in (1, 2, 3, 5, 7):
+        lm = O.NgramLM(order).fit(corpus)
+        tables = DeviceTables.from_words(words, lm)
+        ids = np.zeros((len(texts), S), np.uint8)
+        lens = np.array([len(t) for t in texts], np.int32)
+        for i, t in enumerate(texts):
+            ids[i, :len(t)] = synth.text_to_tokens(t)
+        got = lm_logp_batch(tables, torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)).cpu().numpy()
+        for i, t in enumerate(texts):
+            assert float(got[i]).hex() == lm.logp(t).hex(), (order, t)
+        # LM rerank rule (inference_emg_llm.py:461-464) on device scores
+        if order == 3:
+            a, b = 12, 20
+            f = lambda i: float(got[i]) - 0.002 * len(texts[i])
+            pick = texts[a] if f(a) >= f(b) else texts[b]
+            assert pick == O.rerank_lm(texts[a], texts[b], lm)
+    # teacher-forced token log-prob sums (eval_ar.py:574-589)
+    rng = np.random.RandomState(4)
+    N, Lm = 33, 50
+    lg = (rng.randn(N, Lm, 40) * 3).astype(np.float32)
+    tgt = rng.randint(0, 40, (N, Lm)).astype(np.uint8)
+    ln = rng.randint(0, Lm + 1, N).astype(np.int32)
+    got = rerank_gather_batch(torch.from_numpy(lg).to(dev), torch.from_numpy(tgt).to(dev),
+                              torch.from_numpy(ln).to(dev)).cpu().numpy()
+    lsm = cbind.log_softmax_rows(lg)
+    for u in range(N):
+        tot = 0.0
+        for i in range(ln[u]):
+            tot += float(lsm[u, i, tgt[u, i]])
+        assert float(got[u]).hex() == tot.hex(), u
+
+
+def test_gather_ids_matches_host_histories(dev):
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    words = synth.make_lexicon(50, 1)
+    lm = O.NgramLM(5).fit(synth.make_sentences(words, 200, 2))
+    targets = synth.make_sentences(words, 9, 3, 2, 3)
+    tg, tl = _pack_targets(targets)
+    dec = NSDecoder(DeviceTables.from_words(words, lm), 8, 20, variant="I", lm_weight=0.05)
+    ws = dec.workspace(len(targets))
+    dec.init(ws)
+    hyps = [[[37]] for _ in targets]
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    for t in range(12):
+        dec.synth_logits(ws, 11, 0, tgd, tld, 7.0)
+        dec.step(ws)
+        bp = ws.backptr[t].cpu().numpy().reshape(len(targets), 8)
+        tk = ws.token[t].cpu().numpy().reshape(len(targets), 8)
+        nb = ws.utt.cpu().numpy() & 0xFF
+        for u in range(len(targets)):
+            hyps[u] = [hyps[u][bp[u, r]] + ([] if tk[u, r] == 0xFF else [int(tk[u, r])]) for r in range(nb[u])]
+    ids, lens = dec.gather_ids(ws)
+    ids, lens = ids.cpu().numpy().reshape(len(targets), 8, -1), lens.cpu().numpy().reshape(len(targets), 8)
+    for u in range(len(targets)):
+        for r in range(8):
+            if r < len(hyps[u]):
+                assert list(ids[u, r, :lens[u, r]]) == hyps[u][r]
+            else:
+                assert lens[u, r] == 0
