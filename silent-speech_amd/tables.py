@@ -152,6 +152,37 @@ def _place(keys: np.ndarray, cap: int) -> np.ndarray:
     return slot
 
 
+class NgramCounts:
+    """Character n-gram counts with CharNgramLM's attribute names.
+
+    ``fit`` restates CharNgramLM.fit (scripts/ns_utils.py:99-109): every
+    n-gram of '^' + text.strip().lower() + '$' and its (n-1)-gram context are
+    counted, V collects the characters seen.  ``floor_vsz`` picks the
+    smoothing vocabulary of scripts/ns_utils.py:148 (True) or of the in-file
+    copies (False)."""
+
+    def __init__(self, order: int = 3, floor_vsz: bool = True):
+        self.order = int(order)
+        self.floor_vsz = bool(floor_vsz)
+        self.counts: dict = {}
+        self.context: dict = {}
+        self.V: set = set()
+
+    def fit(self, texts: Iterable[str]) -> "NgramCounts":
+        n = self.order
+        counts, context = self.counts, self.context
+        for t in texts:
+            s = "^" + (t or "").strip().lower() + "$"
+            if len(s) >= n:
+                self.V.update(s)
+            for i in range(len(s) - n + 1):
+                g = s[i:i + n]
+                counts[g] = counts.get(g, 0) + 1
+                c = g[:-1]
+                context[c] = context.get(c, 0) + 1
+        return self
+
+
 class NgramTables:
     """Flat hash tables of one CharNgramLM-like object."""
 

@@ -122,3 +122,17 @@ def test_product_path_refuses_to_run_without_gpu():
     from silent_speech_amd.decoder import DeviceTables
     with pytest.raises(lib.NsdError):
         DeviceTables.from_words(["ab"])
+
+
+def test_package_counts_and_text_generators_match_checker():
+    from silent_speech_amd import synthetic as S
+    words = S.make_lexicon(80, 3)
+    assert words == synth.make_lexicon(80, 3, max_len=8)
+    sents = S.make_sentences(words, 50, 4)
+    assert sents == synth.make_sentences(words, 50, 4)
+    for order in (1, 3, 5):
+        a = T.NgramCounts(order).fit(sents + ["", " x ", "AB"])
+        b = O.NgramLM(order).fit(sents + ["", " x ", "AB"])
+        assert dict(a.counts) == dict(b.counts) and dict(a.context) == dict(b.context) and a.V == b.V
+    tg, tl = S.pack_targets(["ab c", ""])
+    assert tg.tolist() == [[0, 1, 36, 2], [0, 0, 0, 0]] and tl.tolist() == [4, 0]
