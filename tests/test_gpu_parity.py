@@ -170,14 +170,16 @@ def test_batch_512_against_c_checker(dev, variant, beam, order, beta, margin):
 def test_open_lexicon_with_dead_beams(dev):
     """100k-word lexicon over a-z0-9 plus apostrophe words whose prefix node has
     no usable child: exercises random-access trie reads and the fall-back."""
-    words = synth.make_lexicon(100000, 1, synth.BASE_CHARS[:36], 2, 12) + ["don't", "can't", "it's"]
+    # apostrophe words with a prefix no random word shares: at that prefix node the only child is "'",
+    # which the decoder cannot take, so the hypothesis falls back to the neural top-k and stays dead
+    words = synth.make_lexicon(100000, 1, synth.BASE_CHARS[:36], 2, 12) + ["zqxjkvw'a", "wvvqkzx'b", "it's"]
     case = dict(variant="U", beam=32, lm_order=5, beta=0.05, margin=9.0, gamma=1.0, kappa=0.35, alpha=0.6,
                 min_len_for_eos=8, max_new_tokens=24, n_words=0, lex_seed=0, n_corpus=0, corpus_seed=0,
                 n_utts=0, target_seed=0, base_seed=5, name="open100k")
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
     plain = [w for w in words if "'" not in w]
     corpus = synth.make_sentences(plain, 3000, 4)
-    targets = synth.make_sentences(plain, 192, 6, 2, 4) + ["don tx it s", "can t do", "it sx"] * 8
+    targets = synth.make_sentences(plain, 192, 6, 2, 4) + ["zqxjkvw ab it s", "wvvqkzx b c", "it sx"] * 8
     tg, tl = _pack_targets(targets)
     saw_dead = False
     for variant in ("U", "I", "E"):
