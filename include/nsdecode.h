@@ -96,17 +96,46 @@ typedef struct NsdCtxSlot {            /* key: `order-1` symbols */
     uint64_t key;
     double   backoff;                  /* log(1/(C+|V|+1)): value of an unseen n-gram in a seen context */
     double   term;                     /* log((c(ctx+'$')+1)/(C+|V|+1)): the terminal n-gram */
-    uint64_t reserved;
+    uint64_t ctx_id;                   /* index of this context in ctx_recs */
 } NsdCtxSlot;
+
+/* The same counts as a context automaton, which is what nsd_step walks: one
+ * record per seen context, its seen n-grams stored contiguously in ascending
+ * symbol-code order starting at child_base, so
+ *   rec(ctx, sym) = gram_recs[child_base + popcount(symmask & ((1 << sym) - 1))]
+ * when bit `sym` of symmask is set.  A step then costs one direct load per
+ * candidate instead of dependent hash probes; the hash tables above remain
+ * for unseen transitions and for whole-string scoring (nsd_lm_logp). */
+typedef struct NsdCtxRec {
+    double   backoff;
+    double   term;
+    uint64_t symmask;                  /* bit c set: n-gram (ctx, symbol code c) was seen */
+    uint32_t child_base;
+    uint32_t reserved;
+} NsdCtxRec;
+
+typedef struct NsdGramRec {            /* 24 bytes */
+    double   logp;                     /* log((c+1)/(C+|V|+1)) of this n-gram */
+    double   term_next;                /* term of the context reached by appending the symbol */
+    uint32_t next_ctx;                 /* id of that context, NSD_CTX_NONE if it was never seen */
+    uint32_t reserved;
+} NsdGramRec;
+
+#define NSD_CTX_NONE 0xFFFFFFFFu
 
 typedef struct NsdNgramHash {          /* host memory */
     int32_t  order;                    /* 0 = no language model */
-    int32_t  reserved;
+    uint32_t init_ctx;                 /* id of the context of the empty surface ('^' for order 2, the empty
+                                          context for order 1), NSD_CTX_NONE for longer orders */
     uint64_t gram_cap;                 /* power of two */
     uint64_t ctx_cap;                  /* power of two */
     const NsdGramSlot *grams;
     const NsdCtxSlot  *ctxs;
     double   unseen;                   /* log(1/(|V|+1)): any n-gram in an unseen context */
+    uint32_t n_ctx_recs;
+    uint32_t n_gram_recs;
+    const NsdCtxRec  *ctx_recs;
+    const NsdGramRec *gram_recs;
 } NsdNgramHash;
 
 typedef struct NsdTables NsdTables;    /* opaque, device resident, immutable after create */
@@ -135,8 +164,11 @@ typedef struct NsdParams {
 typedef struct NsdBeamState {
     double   *score;     /* device [N*B] accumulated raw score (fp64, as the reference's Python floats) */
     double   *lmsum;     /* device [N*B] running sum of interior n-gram log-probs of the stripped surface */
+    double   *lmsum_e;   /* device [N*B] the same including a pending trailing space */
     uint64_t *ctx;       /* device [N*B] last order-1 symbols of '^' + stripped surface */
     uint64_t *hist;      /* device [N*B] rolling hash of the token history (consumed by batched step functions) */
+    uint32_t *ctx_id;    /* device [N*B] automaton id of ctx, NSD_CTX_NONE if unseen or still shorter than order-1 */
+    uint32_t *ctxe_id;   /* device [N*B] automaton id of ctx followed by the pending space (= ctx_id without one) */
     uint32_t *node;      /* device [N*B] trie node of the current word prefix, or NSD_NODE_DEAD */
     uint32_t *meta;      /* device [N*B] flags | generated length << 8 */
     uint32_t *utt;       /* device [N]   see NSD_U_* */
@@ -159,7 +191,7 @@ int nsd_tables_destroy(NsdTables *t);
 int nsd_tables_order(const NsdTables *t);
 
 /* beams = [(0.0, [BOS], "")] for N utterances (scripts/ns_utils.py:214). */
-int nsd_state_init(const NsdBeamState *st, int32_t N, int32_t B, void *stream);
+int nsd_state_init(const NsdTables *t, const NsdBeamState *st, int32_t N, int32_t B, void *stream);
 
 /* One decode step for N utterances x B beams: the body of the loop at
  * scripts/ns_utils.py:218-275 (and its copies, see NSD_VARIANT_*).

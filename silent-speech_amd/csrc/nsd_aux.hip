@@ -42,6 +42,19 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
     if (order > 0) {
         if (!lm->grams || !lm->ctxs) return NSD_E_NULL;
         if (!is_pow2(lm->gram_cap) || !is_pow2(lm->ctx_cap)) return NSD_E_TABLE;
+        if ((lm->n_ctx_recs && !lm->ctx_recs) || (lm->n_gram_recs && !lm->gram_recs)) return NSD_E_NULL;
+        // every automaton edge must stay inside the arrays
+        for (uint32_t i = 0; i < lm->n_ctx_recs; ++i) {
+            const NsdCtxRec &r = lm->ctx_recs[i];
+            if (r.symmask && (uint64_t)r.child_base + (uint64_t)__builtin_popcountll(r.symmask) > lm->n_gram_recs)
+                return NSD_E_TABLE;
+        }
+        for (uint32_t i = 0; i < lm->n_gram_recs; ++i)
+            if (lm->gram_recs[i].next_ctx != NSD_CTX_NONE && lm->gram_recs[i].next_ctx >= lm->n_ctx_recs)
+                return NSD_E_TABLE;
+        for (uint64_t i = 0; i < lm->ctx_cap; ++i)
+            if (lm->ctxs[i].key != NSD_KEY_EMPTY && lm->ctxs[i].ctx_id >= lm->n_ctx_recs) return NSD_E_TABLE;
+        if (lm->init_ctx != NSD_CTX_NONE && lm->init_ctx >= lm->n_ctx_recs) return NSD_E_TABLE;
     }
     // children of every node must stay inside the array
     for (uint32_t i = 0; i < trie->n_nodes; ++i) {
@@ -64,17 +77,33 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
         if ((e = hipMemcpy(t->grams, lm->grams, gb, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
         if ((e = hipMalloc((void **)&t->ctxs, cb)) != hipSuccess) goto fail;
         if ((e = hipMemcpy(t->ctxs, lm->ctxs, cb, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+        {   // automaton records (at least one element is allocated so that the pointers are never null)
+            const size_t rb = sizeof(NsdCtxRec) * (size_t)(lm->n_ctx_recs ? lm->n_ctx_recs : 1);
+            const size_t qb = sizeof(NsdGramRec) * (size_t)(lm->n_gram_recs ? lm->n_gram_recs : 1);
+            if ((e = hipMalloc((void **)&t->ctx_recs, rb)) != hipSuccess) goto fail;
+            if ((e = hipMalloc((void **)&t->gram_recs, qb)) != hipSuccess) goto fail;
+            if (lm->n_ctx_recs && (e = hipMemcpy(t->ctx_recs, lm->ctx_recs, sizeof(NsdCtxRec) * (size_t)lm->n_ctx_recs,
+                                                 hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+            if (lm->n_gram_recs && (e = hipMemcpy(t->gram_recs, lm->gram_recs, sizeof(NsdGramRec) * (size_t)lm->n_gram_recs,
+                                                  hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+            t->n_ctx_recs = lm->n_ctx_recs;
+            t->n_gram_recs = lm->n_gram_recs;
+            t->init_ctx = lm->init_ctx;
+        }
         t->gram_mask = lm->gram_cap - 1;
         t->ctx_mask = lm->ctx_cap - 1;
         t->unseen = lm->unseen;
         t->ctx_sym_mask = order >= 2 ? ((1ull << (6 * (order - 1))) - 1ull) : 0ull;
     }
+    if (order == 0) t->init_ctx = NSD_CTX_NONE;
     *out = t;
     return NSD_OK;
 fail:
     if (t->nodes) (void)hipFree(t->nodes);
     if (t->grams) (void)hipFree(t->grams);
     if (t->ctxs) (void)hipFree(t->ctxs);
+    if (t->ctx_recs) (void)hipFree(t->ctx_recs);
+    if (t->gram_recs) (void)hipFree(t->gram_recs);
     delete t;
     return (int)e;
 }
@@ -85,6 +114,8 @@ extern "C" int nsd_tables_destroy(NsdTables *t)
     if (t->nodes) (void)hipFree(t->nodes);
     if (t->grams) (void)hipFree(t->grams);
     if (t->ctxs) (void)hipFree(t->ctxs);
+    if (t->ctx_recs) (void)hipFree(t->ctx_recs);
+    if (t->gram_recs) (void)hipFree(t->gram_recs);
     delete t;
     return NSD_OK;
 }
@@ -94,7 +125,7 @@ extern "C" int nsd_tables_order(const NsdTables *t) { return t ? t->order : NSD_
 // ---------------------------------------------------------------------
 // state init
 // ---------------------------------------------------------------------
-__global__ void nsd_state_init_kernel(NsdBeamState st, int N, int B)
+__global__ void nsd_state_init_kernel(NsdBeamState st, int N, int B, uint64_t ctx0, uint32_t id0)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u == 0 && st.done_count) *st.done_count = 0;
@@ -102,20 +133,27 @@ __global__ void nsd_state_init_kernel(NsdBeamState st, int N, int B)
     const size_t i = (size_t)u * B;
     st.score[i] = 0.0;
     st.lmsum[i] = 0.0;
-    st.ctx[i] = NSD_SYM_HAT;
+    st.lmsum_e[i] = 0.0;
+    st.ctx[i] = ctx0;
     st.hist[i] = NSD_HIST0;
+    st.ctx_id[i] = id0;
+    st.ctxe_id[i] = id0;
     st.node[i] = 0;
     st.meta[i] = 0;
     st.utt[u] = 1u;            // one hypothesis, not done, zero steps
 }
 
-extern "C" int nsd_state_init(const NsdBeamState *st, int32_t N, int32_t B, void *stream)
+extern "C" int nsd_state_init(const NsdTables *t, const NsdBeamState *st, int32_t N, int32_t B, void *stream)
 {
     if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
     if (N < 0) return NSD_E_SIZE;
     if (N == 0) return NSD_OK;
-    if (!st || !st->score || !st->lmsum || !st->ctx || !st->hist || !st->node || !st->meta || !st->utt) return NSD_E_NULL;
-    hipLaunchKernelGGL(nsd_state_init_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *st, N, B);
+    if (!t || !st || !st->score || !st->lmsum || !st->lmsum_e || !st->ctx || !st->hist || !st->ctx_id ||
+        !st->ctxe_id || !st->node || !st->meta || !st->utt) return NSD_E_NULL;
+    // context of the empty surface: '^' cut to the last order-1 symbols
+    const uint64_t ctx0 = t->order >= 2 ? (uint64_t)NSD_SYM_HAT : 0ull;
+    hipLaunchKernelGGL(nsd_state_init_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *st, N, B,
+                       ctx0, t->init_ctx);
     return (int)hipGetLastError();
 }
 

@@ -8,10 +8,15 @@ struct NsdTables {
     NsdTrieNode *nodes;
     uint32_t     n_nodes;
     int32_t      order;
-    NsdGramSlot *grams;
+    NsdGramSlot *grams;          // hash: n-gram key -> logp (whole-string scoring)
     uint64_t     gram_mask;      // cap - 1
-    NsdCtxSlot  *ctxs;
+    NsdCtxSlot  *ctxs;           // hash: context key -> backoff, term, automaton id
     uint64_t     ctx_mask;       // cap - 1
+    NsdCtxRec   *ctx_recs;       // automaton: one record per seen context
+    NsdGramRec  *gram_recs;      // automaton: seen n-grams grouped by context
+    uint32_t     n_ctx_recs, n_gram_recs;
+    uint32_t     init_ctx;       // automaton id of the empty surface's context, or NSD_CTX_NONE
+    uint32_t     pad;
     double       unseen;
     uint64_t     ctx_sym_mask;   // keeps the last order-1 symbols of a packed context
 };
@@ -170,6 +175,59 @@ NSD_D double nsd_gram_logp(const NsdTables &t, uint64_t ctx, uint32_t sym, doubl
 NSD_D uint64_t nsd_ctx_shift(const NsdTables &t, uint64_t ctx, uint32_t sym)
 {
     return ((ctx << 6) | sym) & t.ctx_sym_mask;
+}
+
+// One transition of the context automaton.  The hypothesis' effective context
+// has `me` symbols ('^' + surface), packed key `ctxe`, automaton id `ide`
+// (NSD_CTX_NONE when unseen or shorter than order-1) and, when the id is
+// valid, the record fields symmask / lmbase / backoff.  Appending symbol code
+// `sym`:
+//   has_int  the n-gram window ending at the new symbol exists (me+1 >= order);
+//            its log-prob is `lint`
+//   full_new the new context has order-1 symbols, i.e. the terminal window of
+//            the extended text exists (me+2 >= order); its log-prob is `term`
+//   ctxn / next_id  key and automaton id of the new context
+struct NsdLmStep {
+    double   lint, term;
+    uint64_t ctxn;
+    uint32_t next_id;
+    bool     has_int, full_new;
+};
+
+NSD_D NsdLmStep nsd_lm_advance(const NsdTables &t, int me, uint64_t ctxe, uint32_t ide,
+                               uint64_t symmask, uint32_t lmbase, double backoff, uint32_t sym)
+{
+    NsdLmStep r;
+    const int order = t.order;
+    r.has_int = me + 1 >= order;
+    r.full_new = me + 2 >= order;
+    r.ctxn = nsd_ctx_shift(t, ctxe, sym);
+    r.next_id = NSD_CTX_NONE;
+    r.lint = 0.0;
+    r.term = 0.0;
+    bool resolved = false;
+    if (r.has_int) {
+        if (ide != NSD_CTX_NONE) {
+            if ((symmask >> sym) & 1ull) {
+                const NsdGramRec *g = t.gram_recs + lmbase + __popcll(symmask & ((1ull << sym) - 1ull));
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(g);     // logp, term_next
+                r.lint = __longlong_as_double((long long)a.x);
+                r.term = __longlong_as_double((long long)a.y);
+                r.next_id = g->next_ctx;
+                resolved = true;
+            } else {
+                r.lint = backoff;
+            }
+        } else {
+            r.lint = t.unseen;
+        }
+    }
+    if (r.full_new && !resolved) {
+        const NsdCtxSlot *s = nsd_ctx_find(t, r.ctxn);
+        r.next_id = s ? (uint32_t)s->ctx_id : NSD_CTX_NONE;
+        r.term = s ? s->term : t.unseen;
+    }
+    return r;
 }
 
 // compiler + LDS ordering point between lanes of one wave

@@ -1,14 +1,18 @@
 // nsd_step: one NS decode step for N utterances x B beams (gfx950).
 //
-// Work split: one 64-lane wave per utterance.
-//   phase 1  lane b loads hypothesis b's state, its trie node record and the
-//            per-hypothesis n-gram context values into LDS
-//   phase 2  8 lanes per logits row (5 consecutive logits per lane), 8 rows
-//            per pass: deterministic log-softmax, lexicon mask applied, the
-//            allowed (hypothesis, token) pairs are compacted into an LDS list
-//   phase 3  one lane per listed candidate: n-gram lookups, beta/gamma/kappa
-//            fusion, fp64 score and pruning key
-//   phase 4  top-B of the list by (key descending, emission order ascending)
+// Work split: one 64-lane wave per utterance, no block-level barrier.
+//   phase 1  lane b loads hypothesis b's state, then (second dependent hop)
+//            its trie node record and its n-gram context record, into LDS
+//   phase 2  8 lanes per logits row (5 consecutive logits per lane), live rows
+//            only, 8 rows per pass: deterministic log-softmax, lexicon mask
+//            applied, the allowed (hypothesis, token) pairs are compacted into
+//            an LDS candidate list
+//   phase 3  one lane per listed candidate: one context-automaton record load
+//            (third hop), beta/gamma/kappa fusion, fp64 score and pruning key
+//   phase 4  top-B of the list: every lane counts, over broadcast LDS reads of
+//            all keys, how many beat its own candidate; that count is the rank
+//            (exact score ties take a slower pass that also compares the
+//            emission order)
 //   phase 5  lane r writes surviving hypothesis r: new score, n-gram state,
 //            trie child, flags, history hash, back-pointer and token
 //
@@ -20,7 +24,7 @@
 namespace {
 
 enum : uint32_t { K_CHAR = 0, K_EOS = 1, K_CARRY = 2, K_FALLBACK = 3 };
-constexpr uint32_t CONSUMED = 0x80000000u;
+constexpr uint32_t SEL_NONE = 0xFFFFFFFFu;
 
 // candidate info word: tok[0:6) kind[6:8) order[8:20) (= parent*64 + w)
 NSD_D uint32_t pack_info(uint32_t tok, uint32_t kind, uint32_t w, uint32_t parent)
@@ -41,13 +45,15 @@ struct StepArgs {
 };
 
 struct WaveLds {
-    double   *bScore, *bG, *bGe, *bBo;
-    uint64_t *bCtx, *bCtxe, *bHist, *bMask;
-    uint32_t *bChild, *bMeta, *bNode;
+    double   *bScore, *bG, *bGe, *bBo, *bTermS;
+    uint64_t *bCtx, *bHist, *bMask, *bSym;
+    uint32_t *bChild, *bLmBase, *bMeta, *bNode, *bCtxId, *bCtxeId, *live, *sel;
     double   *cKey, *cScore;
     uint32_t *cInfo;
     float    *rowbuf;
 };
+
+constexpr int BEAM_BYTES = 9 * 8 + 8 * 4;
 
 NSD_D WaveLds carve(unsigned char *base, int B, uint32_t maxc, bool with_score)
 {
@@ -57,32 +63,48 @@ NSD_D WaveLds carve(unsigned char *base, int B, uint32_t maxc, bool with_score)
     w.bG     = (double *)p;   p += 8 * B;
     w.bGe    = (double *)p;   p += 8 * B;
     w.bBo    = (double *)p;   p += 8 * B;
+    w.bTermS = (double *)p;   p += 8 * B;
     w.bCtx   = (uint64_t *)p; p += 8 * B;
-    w.bCtxe  = (uint64_t *)p; p += 8 * B;
     w.bHist  = (uint64_t *)p; p += 8 * B;
     w.bMask  = (uint64_t *)p; p += 8 * B;
+    w.bSym   = (uint64_t *)p; p += 8 * B;
     w.cKey   = (double *)p;   p += 8 * (size_t)maxc;
     w.cScore = (double *)p;   if (with_score) p += 8 * (size_t)maxc;
     w.cInfo  = (uint32_t *)p; p += 4 * (size_t)maxc;
     w.bChild = (uint32_t *)p; p += 4 * B;
+    w.bLmBase = (uint32_t *)p; p += 4 * B;
     w.bMeta  = (uint32_t *)p; p += 4 * B;
     w.bNode  = (uint32_t *)p; p += 4 * B;
+    w.bCtxId = (uint32_t *)p; p += 4 * B;
+    w.bCtxeId = (uint32_t *)p; p += 4 * B;
+    w.live   = (uint32_t *)p; p += 4 * B;
+    w.sel    = (uint32_t *)p; p += 4 * B;
     w.rowbuf = (float *)p;
     return w;
+}
+
+// most candidates one live hypothesis can emit (a carried, finished one emits exactly one)
+NSD_HD uint32_t max_cands_per_beam(int B, int variant)
+{
+    const uint32_t kfb = (uint32_t)(B < NSD_V ? B : NSD_V);
+    const uint32_t lex = NSD_NBASE + (variant == NSD_VARIANT_I ? 0u : 1u);   // 37 characters (+ EOS)
+    const uint32_t fb = kfb + (variant == NSD_VARIANT_U ? 1u : 0u);
+    return lex > fb ? lex : fb;
 }
 
 } // namespace
 
 static size_t nsd_step_lds_per_wave(int B, int variant, uint32_t *maxc_out)
 {
-    uint32_t maxc = (uint32_t)B * 41u;
-    size_t bytes = (size_t)B * (8 * 8 + 4 * 3) + (size_t)maxc * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) + 8 * 40 * 4;
+    uint32_t maxc = (uint32_t)B * max_cands_per_beam(B, variant);
+    maxc = (maxc + 1u) & ~1u;
+    size_t bytes = (size_t)B * BEAM_BYTES + (size_t)maxc * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) + 8 * 40 * 4;
     bytes = (bytes + 15) & ~(size_t)15;
     if (maxc_out) *maxc_out = maxc;
     return bytes;
 }
 
-template <int WAVES>
+template <int WAVES, int VARIANT>
 __global__ void __launch_bounds__(WAVES * 64)
 nsd_step_kernel(StepArgs a, NsdParams P)
 {
@@ -101,8 +123,9 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         if (!aliased) {
             if (lane < nbeams) {
                 const size_t i = (size_t)u * B + lane;
-                a.out.score[i] = a.in.score[i]; a.out.lmsum[i] = a.in.lmsum[i];
+                a.out.score[i] = a.in.score[i]; a.out.lmsum[i] = a.in.lmsum[i]; a.out.lmsum_e[i] = a.in.lmsum_e[i];
                 a.out.ctx[i] = a.in.ctx[i];     a.out.hist[i] = a.in.hist[i];
+                a.out.ctx_id[i] = a.in.ctx_id[i]; a.out.ctxe_id[i] = a.in.ctxe_id[i];
                 a.out.node[i] = a.in.node[i];   a.out.meta[i] = a.in.meta[i];
             }
             if (lane == 0) a.out.utt[u] = um;
@@ -110,48 +133,66 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         return;
     }
 
-    const int variant = P.variant;
     const bool use_lm = P.use_lm != 0 && a.tab.order > 0;
     const int order = a.tab.order;
-    WaveLds L = carve(smem + (size_t)wid * a.lds_per_wave, B, a.maxc, variant == NSD_VARIANT_E);
+    WaveLds L = carve(smem + (size_t)wid * a.lds_per_wave, B, a.maxc, VARIANT == NSD_VARIANT_E);
 
     // ---------------- phase 1: hypothesis state -> LDS ----------------
+    bool my_live = false;
+    if (lane < B) L.sel[lane] = SEL_NONE;
     if (lane < nbeams) {
         const size_t i = (size_t)u * B + lane;
+        const uint32_t meta = a.in.meta[i];
+        const uint32_t node = a.in.node[i];
+        const uint32_t ctx_id = a.in.ctx_id[i];
+        const uint32_t ctxe_id = a.in.ctxe_id[i];
         const double score = a.in.score[i];
         const double G = a.in.lmsum[i];
+        const double Ge = a.in.lmsum_e[i];
         const uint64_t ctx = a.in.ctx[i];
         const uint64_t hist = a.in.hist[i];
-        const uint32_t node = a.in.node[i];
-        uint32_t meta = a.in.meta[i];
         const uint32_t flags = meta & 0xffu;
         const int glen = (int)(meta >> 8);
-        uint64_t mask = 0;
-        uint32_t child = 0;
-        const bool live = !(flags & NSD_F_FINISHED);
-        if (live && !(flags & NSD_F_DEAD) && node != NSD_NODE_DEAD) {
-            const ulonglong2 rec = *reinterpret_cast<const ulonglong2 *>(&a.tab.nodes[node]);
-            mask = rec.x;
-            child = (uint32_t)rec.y;
-        }
-        if ((mask & ((1ull << NSD_NBASE) - 1)) == 0) mask = 0;     // nothing lexicon-consistent: fall-back
-        double Ge = G, bo = 0.0;
-        uint64_t ctxe = ctx;
-        if (use_lm && live && mask != 0) {
+        my_live = !(flags & NSD_F_FINISHED);
+        // second hop: trie node and n-gram context records
+        uint64_t sym = 0;
+        uint32_t lmbase = 0;
+        double bo = 0.0, term_s = 0.0;
+        const bool in_lex = my_live && !(flags & NSD_F_DEAD) && node != NSD_NODE_DEAD;
+        ulonglong2 nrec = {0ull, 0ull};
+        if (in_lex) nrec = *reinterpret_cast<const ulonglong2 *>(&a.tab.nodes[node]);
+        if (use_lm && in_lex) {
             const int pend = (flags & NSD_F_PENDING_SPACE) ? 1 : 0;
-            const int ms = 1 + glen - pend;            // symbols in '^' + stripped surface
-            int me = ms;
-            if (pend) {
-                if (ms + 1 >= order) Ge = G + nsd_gram_logp(a.tab, ctx, NSD_SPACE + 1u, nsd_ctx_backoff(a.tab, ctx));
-                ctxe = nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u);
-                me = ms + 1;
+            const int ms = 1 + glen - pend;                        // symbols in '^' + stripped surface
+            if (ctxe_id != NSD_CTX_NONE) {
+                const NsdCtxRec *r = a.tab.ctx_recs + ctxe_id;
+                const ulonglong2 q0 = reinterpret_cast<const ulonglong2 *>(r)[0];   // backoff, term
+                const ulonglong2 q1 = reinterpret_cast<const ulonglong2 *>(r)[1];   // symmask, child_base
+                bo = __longlong_as_double((long long)q0.x);
+                sym = q1.x;
+                lmbase = (uint32_t)q1.y;
+                if (!pend) term_s = __longlong_as_double((long long)q0.y);
             }
-            if (me + 1 >= order) bo = nsd_ctx_backoff(a.tab, ctxe);
+            if (ms + 1 >= order) {                                 // terminal window of the stripped surface exists
+                if (pend) term_s = ctx_id != NSD_CTX_NONE ? a.tab.ctx_recs[ctx_id].term : a.tab.unseen;
+                else if (ctxe_id == NSD_CTX_NONE) term_s = a.tab.unseen;
+            }
         }
-        L.bScore[lane] = score; L.bG[lane] = G; L.bGe[lane] = Ge; L.bBo[lane] = bo;
-        L.bCtx[lane] = ctx; L.bCtxe[lane] = ctxe; L.bHist[lane] = hist; L.bMask[lane] = mask;
-        L.bChild[lane] = child; L.bMeta[lane] = meta; L.bNode[lane] = node;
+        uint64_t mask = nrec.x;
+        const uint32_t child = (uint32_t)nrec.y;
+        if ((mask & ((1ull << NSD_NBASE) - 1)) == 0) mask = 0;     // nothing lexicon-consistent: fall-back
+        L.bScore[lane] = score; L.bG[lane] = G; L.bGe[lane] = Ge; L.bBo[lane] = bo; L.bTermS[lane] = term_s;
+        L.bCtx[lane] = ctx; L.bHist[lane] = hist; L.bMask[lane] = mask; L.bSym[lane] = sym;
+        L.bChild[lane] = child; L.bLmBase[lane] = lmbase; L.bMeta[lane] = meta; L.bNode[lane] = node;
+        L.bCtxId[lane] = ctx_id; L.bCtxeId[lane] = ctxe_id;
         if (a.mask_dbg) a.mask_dbg[i] = mask & ((1ull << NSD_NBASE) - 1);
+    }
+    const uint64_t live_mask = __ballot(my_live);
+    const int nlive = __popcll(live_mask);
+    if (my_live) {
+        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(live_mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)live_mask, 0u));
+        L.live[pre] = (uint32_t)lane;
     }
     nsd_wave_sync();
 
@@ -171,12 +212,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     };
 
     const int j = lane & 7;
-    for (int pass = 0; pass * 8 < nbeams; ++pass) {
-        const int r = pass * 8 + (lane >> 3);
-        const bool rowvalid = r < nbeams;
-        const uint32_t meta = rowvalid ? L.bMeta[r] : NSD_F_FINISHED;
-        const bool live = rowvalid && !(meta & NSD_F_FINISHED);
-        const uint64_t mask = rowvalid ? L.bMask[r] : 0;
+    for (int pass = 0; pass * 8 < nlive; ++pass) {
+        const int slot = pass * 8 + (lane >> 3);
+        const bool live = slot < nlive;
+        const int r = live ? (int)L.live[slot] : 0;
+        const uint32_t meta = L.bMeta[r];
+        const uint64_t mask = live ? L.bMask[r] : 0;
         const int glen = (int)(meta >> 8);
         float x[5];
         if (live) {
@@ -191,8 +232,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 
         const bool whole = (mask >> 37) & 1;
         const bool pend = (meta & NSD_F_PENDING_SPACE) != 0;
-        const bool eos_u = live && variant == NSD_VARIANT_U && P.allow_eos_anytime;
-        const bool eos_e = live && variant == NSD_VARIANT_E && mask != 0 &&
+        const bool eos_u = live && VARIANT == NSD_VARIANT_U && P.allow_eos_anytime;
+        const bool eos_e = live && VARIANT == NSD_VARIANT_E && mask != 0 &&
                            glen >= P.min_len_for_eos && (pend || whole);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -200,8 +241,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             const bool is_char = live && v < NSD_NBASE && ((mask >> v) & 1);
             const bool is_eos = (v == NSD_EOS) && (eos_u || eos_e);
             uint32_t w = v, kind = K_CHAR;
-            if (variant == NSD_VARIANT_U) w = v + 1;
-            if (is_eos) { kind = K_EOS; w = (variant == NSD_VARIANT_U) ? 0u : 40u; }
+            if (VARIANT == NSD_VARIANT_U) w = v + 1;
+            if (is_eos) { kind = K_EOS; w = (VARIANT == NSD_VARIANT_U) ? 0u : 40u; }
             emit(is_char || is_eos, x[k], pack_info(v, kind, w, (uint32_t)r));
         }
 
@@ -213,30 +254,27 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             for (int k = 0; k < 5; ++k) rb[j * 5 + k] = x[k];
             nsd_wave_sync();
             int kfb = B;
-            if (variant == NSD_VARIANT_U) { if (kfb > NSD_V) kfb = NSD_V; }
+            if (VARIANT == NSD_VARIANT_U) { if (kfb > NSD_V) kfb = NSD_V; }
             else if (kfb > NSD_V) { kfb = NSD_V; if (fb) err_topk = true; }
-            uint32_t rank[5];
+            uint32_t rank[5] = {0, 0, 0, 0, 0};
+#pragma unroll 1
+            for (int i = 0; i < NSD_V; ++i) {
+                const float o = rb[i];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int v = j * 5 + k;
-                uint32_t c = 0;
-                for (int i = 0; i < NSD_V; ++i) {
-                    const float o = rb[i];
-                    c += (o > x[k] || (o == x[k] && i < v)) ? 1u : 0u;
-                }
-                rank[k] = c;
+                for (int k = 0; k < 5; ++k)
+                    rank[k] += (o > x[k] || (o == x[k] && i < j * 5 + k)) ? 1u : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const uint32_t v = (uint32_t)(j * 5 + k);
-                const uint32_t w = rank[k] + (variant == NSD_VARIANT_U ? 1u : 0u);
+                const uint32_t w = rank[k] + (VARIANT == NSD_VARIANT_U ? 1u : 0u);
                 emit(fb && rank[k] < (uint32_t)kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)r));
             }
             nsd_wave_sync();
         }
     }
     {   // finished hypotheses compete unchanged (ns_utils.py:222-224)
-        const bool carry = lane < nbeams && (L.bMeta[lane] & NSD_F_FINISHED);
+        const bool carry = lane < nbeams && !my_live;
         emit(carry, 0.0f, pack_info(0x3f, K_CARRY, 0, (uint32_t)lane));
     }
     nsd_wave_sync();
@@ -256,41 +294,38 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             Lnew = glen > 1 ? glen : 1;
         } else if (kind == K_FALLBACK) {
             score = sb + (lp - P.gamma);
-        } else if (kind == K_EOS && variant == NSD_VARIANT_U) {
+        } else if (kind == K_EOS && VARIANT == NSD_VARIANT_U) {
             score = sb + lp;
         } else {
             const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
             const int ms = 1 + glen - pend;
             const bool whole = (L.bMask[p] >> 37) & 1;
             double add = lp;
-            if (kind == K_EOS) {                       // variant E boundary EOS (eval_ar.py:290-296)
-                add -= P.eos_len_nudge * (double)glen;
-                if (use_lm && glen > 0) {
-                    double lg = L.bG[p];
-                    if (ms + 1 >= order) lg = lg + nsd_ctx_term(a.tab, L.bCtx[p]);
-                    add += P.beta * lg;
+            if (kind == K_EOS || tok == NSD_SPACE) {
+                // both score the stripped surface: logp(surf + " ") == logp(surf)
+                double lg = L.bG[p];
+                if (ms + 1 >= order) lg = lg + L.bTermS[p];
+                if (kind == K_EOS) {                   // variant E boundary EOS (eval_ar.py:290-296)
+                    add -= P.eos_len_nudge * (double)glen;
+                    if (use_lm && glen > 0) add += P.beta * lg;
+                } else {
+                    if (use_lm) add += P.beta * lg;
+                    if (!whole) add -= P.gamma;
+                    if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
                 }
-            } else if (tok == NSD_SPACE) {
-                if (use_lm) {
-                    double lg = L.bG[p];               // logp(surf + " ") == logp(surf)
-                    if (ms + 1 >= order) lg = lg + nsd_ctx_term(a.tab, L.bCtx[p]);
-                    add += P.beta * lg;
-                }
-                if (!whole) add -= P.gamma;
-                if (variant == NSD_VARIANT_E && whole) add += P.kappa;
-            } else {
-                if (use_lm) {
-                    const int me = ms + pend;
-                    const uint64_t ctxe = L.bCtxe[p];
-                    double lg = L.bGe[p];
-                    if (me + 1 >= order) lg = lg + nsd_gram_logp(a.tab, ctxe, tok + 1u, L.bBo[p]);
-                    if (me + 2 >= order) lg = lg + nsd_ctx_term(a.tab, nsd_ctx_shift(a.tab, ctxe, tok + 1u));
-                    add += P.beta * lg;
-                }
+            } else if (use_lm) {
+                const uint64_t ctx = L.bCtx[p];
+                const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p],
+                                                   L.bBo[p], tok + 1u);
+                double lg = L.bGe[p];
+                if (s.has_int) lg = lg + s.lint;
+                if (s.full_new) lg = lg + s.term;
+                add += P.beta * lg;
             }
             score = sb + add;
         }
-        if (variant == NSD_VARIANT_E) {
+        if (VARIANT == NSD_VARIANT_E) {
             L.cScore[i] = score;
             L.cKey[i] = score / P.len_denom[Lnew];
         } else {
@@ -301,53 +336,54 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 
     // ---------------- phase 4: top-B by (key desc, emission order asc) ----------------
     const int nsel = (int)C < B ? (int)C : B;
-    uint32_t mysel = 0;
+    for (uint32_t base = 0; base < C; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < C;
+        const double mk = valid ? L.cKey[i] : 0.0;
+        uint32_t rank = 0;
+#pragma unroll 4
+        for (uint32_t q = 0; q < C; ++q) rank += (L.cKey[q] > mk) ? 1u : 0u;
+        if (valid && rank < (uint32_t)nsel) L.sel[rank] = i;
+    }
+    nsd_wave_sync();
     {
-        double myk = 0.0;
-        uint32_t myt = 0xFFFFFFFFu;
-        bool stale = true;
-        for (int r = 0; r < nsel; ++r) {
-            if (stale) {
-                myt = 0xFFFFFFFFu; myk = -__builtin_inf();
-                for (uint32_t i = lane; i < C; i += 64) {
-                    const uint32_t info = L.cInfo[i];
-                    if (info & CONSUMED) continue;
-                    const double k = L.cKey[i];
-                    const uint32_t t = (((info >> 8) & 0xFFFu) << 12) | i;
-                    if (myt == 0xFFFFFFFFu || k > myk || (k == myk && t < myt)) { myk = k; myt = t; }
+        const bool hole = lane < nsel && L.sel[lane] == SEL_NONE;
+        if (__ballot(hole) != 0) {
+            // exact ties among the keys: redo with the emission order as tie-break
+            nsd_wave_sync();
+            for (uint32_t base = 0; base < C; base += 64) {
+                const uint32_t i = base + lane;
+                const bool valid = i < C;
+                const double mk = valid ? L.cKey[i] : 0.0;
+                const uint32_t mo = valid ? ((L.cInfo[i] >> 8) & 0xFFFu) : 0u;
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < C; ++q) {
+                    const double k = L.cKey[q];
+                    const uint32_t o = (L.cInfo[q] >> 8) & 0xFFFu;
+                    rank += (k > mk || (k == mk && (o < mo || (o == mo && q < i)))) ? 1u : 0u;
                 }
-                stale = false;
+                if (valid && rank < (uint32_t)nsel) L.sel[rank] = i;
             }
-            double bk = myk;
-            uint32_t bt = myt;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double ok = __shfl_xor(bk, off);
-                const uint32_t ot = __shfl_xor(bt, off);
-                const bool take = (ot != 0xFFFFFFFFu) && (bt == 0xFFFFFFFFu || ok > bk || (ok == bk && ot < bt));
-                if (take) { bk = ok; bt = ot; }
-            }
-            const uint32_t widx = bt & 0xFFFu;
-            if (lane == r) mysel = widx;
-            if ((int)(widx & 63u) == lane) { L.cInfo[widx] |= CONSUMED; stale = true; }
+            nsd_wave_sync();
         }
     }
-
-    nsd_wave_sync();
 
     // ---------------- phase 5: write the surviving hypotheses ----------------
     bool fin = true;
     if (lane < nsel) {
+        uint32_t mysel = L.sel[lane];
+        if (mysel >= C) mysel = 0;                 // only reachable with NaN keys
         const uint32_t info = L.cInfo[mysel];
         const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = (info >> 14) & 0x3f;
-        const double score = (variant == NSD_VARIANT_E) ? L.cScore[mysel] : L.cKey[mysel];
+        const double score = (VARIANT == NSD_VARIANT_E) ? L.cScore[mysel] : L.cKey[mysel];
         uint32_t meta = L.bMeta[p];
         uint32_t flags = meta & 0xffu;
         int glen = (int)(meta >> 8);
-        double G = L.bG[p];
+        double G = L.bG[p], Ge = L.bGe[p];
         uint64_t ctx = L.bCtx[p];
         uint64_t hist = L.bHist[p];
         uint32_t node = L.bNode[p];
+        uint32_t ctx_id = L.bCtxId[p], ctxe_id = L.bCtxeId[p];
         uint8_t out_tok = NSD_TOKEN_CARRY;
         if (kind != K_CARRY) {
             out_tok = (uint8_t)tok;
@@ -360,16 +396,26 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 if (tok == NSD_EOS) flags |= NSD_F_FINISHED;
                 node = NSD_NODE_DEAD;
             } else if (tok == NSD_SPACE) {
+                // The space joins the LM sum only once a character follows it: keep the stripped state
+                // and prepare the effective one (context + space).  A hypothesis with a pending space
+                // sits at the trie root, which never allows a space, so pend == 0 here.
+                if (use_lm) {
+                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctx, ctx_id, L.bSym[p], L.bLmBase[p],
+                                                       L.bBo[p], NSD_SPACE + 1u);
+                    Ge = s.has_int ? G + s.lint : G;
+                    ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
+                }
                 flags |= NSD_F_PENDING_SPACE;
                 node = 0;
             } else {
                 if (use_lm) {
-                    const int ms = 1 + glen - pend;
-                    const int me = ms + pend;
-                    const uint64_t ctxe = L.bCtxe[p];
-                    G = L.bGe[p];
-                    if (me + 1 >= order) G = G + nsd_gram_logp(a.tab, ctxe, tok + 1u, L.bBo[p]);
-                    ctx = nsd_ctx_shift(a.tab, ctxe, tok + 1u);
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, ctxe_id, L.bSym[p], L.bLmBase[p],
+                                                       L.bBo[p], tok + 1u);
+                    G = s.has_int ? Ge + s.lint : Ge;
+                    Ge = G;
+                    ctx = s.ctxn;
+                    ctx_id = ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
                 }
                 flags &= ~NSD_F_PENDING_SPACE;
                 const uint64_t m = L.bMask[p];
@@ -380,7 +426,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         meta = flags | ((uint32_t)glen << 8);
         fin = (flags & NSD_F_FINISHED) != 0;
         const size_t o = (size_t)u * B + lane;
-        a.out.score[o] = score; a.out.lmsum[o] = G; a.out.ctx[o] = ctx; a.out.hist[o] = hist;
+        a.out.score[o] = score; a.out.lmsum[o] = G; a.out.lmsum_e[o] = Ge; a.out.ctx[o] = ctx; a.out.hist[o] = hist;
+        a.out.ctx_id[o] = ctx_id; a.out.ctxe_id[o] = ctxe_id;
         a.out.node[o] = node;   a.out.meta[o] = meta;
         a.backptr[o] = (uint8_t)p;
         a.token[o] = out_tok;
@@ -394,6 +441,18 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         a.out.utt[u] = nu;
         if (all_fin && a.out.done_count) atomicAdd(a.out.done_count, 1u);
     }
+}
+
+template <int VARIANT>
+static void launch_variant(const StepArgs &a, const NsdParams &p, int N, hipStream_t s)
+{
+    // waves per workgroup: as many as keep a workgroup's LDS at or under 40 KiB (4 workgroups per CU)
+    if (a.lds_per_wave * 4u <= 40960u)
+        hipLaunchKernelGGL((nsd_step_kernel<4, VARIANT>), dim3((N + 3) / 4), dim3(256), a.lds_per_wave * 4u, s, a, p);
+    else if (a.lds_per_wave * 2u <= 40960u)
+        hipLaunchKernelGGL((nsd_step_kernel<2, VARIANT>), dim3((N + 1) / 2), dim3(128), a.lds_per_wave * 2u, s, a, p);
+    else
+        hipLaunchKernelGGL((nsd_step_kernel<1, VARIANT>), dim3(N), dim3(64), a.lds_per_wave, s, a, p);
 }
 
 extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
@@ -414,13 +473,10 @@ extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *log
     a.N = N; a.B = B;
     a.lds_per_wave = (uint32_t)nsd_step_lds_per_wave(B, p->variant, &a.maxc);
     hipStream_t s = (hipStream_t)stream;
-    // waves per workgroup chosen so that a workgroup's LDS stays under 64 KiB
-    if (a.lds_per_wave * 4u <= 65536u) {
-        hipLaunchKernelGGL(nsd_step_kernel<4>, dim3((N + 3) / 4), dim3(256), a.lds_per_wave * 4u, s, a, *p);
-    } else if (a.lds_per_wave * 2u <= 65536u) {
-        hipLaunchKernelGGL(nsd_step_kernel<2>, dim3((N + 1) / 2), dim3(128), a.lds_per_wave * 2u, s, a, *p);
-    } else {
-        hipLaunchKernelGGL(nsd_step_kernel<1>, dim3(N), dim3(64), a.lds_per_wave, s, a, *p);
+    switch (p->variant) {
+    case NSD_VARIANT_U: launch_variant<NSD_VARIANT_U>(a, *p, N, s); break;
+    case NSD_VARIANT_I: launch_variant<NSD_VARIANT_I>(a, *p, N, s); break;
+    default:            launch_variant<NSD_VARIANT_E>(a, *p, N, s); break;
     }
     return (int)hipGetLastError();
 }

@@ -47,8 +47,13 @@ class DeviceTables:
         if ngram is not None:
             self._g = np.ascontiguousarray(ngram.grams)
             self._c = np.ascontiguousarray(ngram.ctxs)
-            lm = _lib.NgramHash(ngram.order, 0, self._g.shape[0], self._c.shape[0],
-                                _lib.np_ptr(self._g), _lib.np_ptr(self._c), ngram.unseen)
+            self._cr = np.ascontiguousarray(ngram.ctx_recs)
+            self._gr = np.ascontiguousarray(ngram.gram_recs)
+            lm = _lib.NgramHash(ngram.order, ngram.init_ctx, self._g.shape[0], self._c.shape[0],
+                                _lib.np_ptr(self._g), _lib.np_ptr(self._c), ngram.unseen,
+                                self._cr.shape[0], self._gr.shape[0],
+                                _lib.np_ptr(self._cr) if self._cr.shape[0] else None,
+                                _lib.np_ptr(self._gr) if self._gr.shape[0] else None)
         h = C.c_void_p()
         _lib.check(L.nsd_tables_create(C.byref(trie), C.byref(lm) if lm is not None else None, C.byref(h)),
                    "nsd_tables_create")
@@ -96,8 +101,11 @@ class Workspace:
         kw = dict(device=device)
         self.score = torch.zeros(NB, dtype=torch.float64, **kw)
         self.lmsum = torch.zeros(NB, dtype=torch.float64, **kw)
+        self.lmsum_e = torch.zeros(NB, dtype=torch.float64, **kw)
         self.ctx = torch.zeros(NB, dtype=torch.int64, **kw)
         self.hist = torch.zeros(NB, dtype=torch.int64, **kw)
+        self.ctx_id = torch.zeros(NB, dtype=torch.int32, **kw)
+        self.ctxe_id = torch.zeros(NB, dtype=torch.int32, **kw)
         self.node = torch.zeros(NB, dtype=torch.int32, **kw)
         self.meta = torch.zeros(NB, dtype=torch.int32, **kw)
         self.utt = torch.zeros(max(N, 1), dtype=torch.int32, **kw)
@@ -109,8 +117,9 @@ class Workspace:
         self.out_ids = torch.zeros(max(N, 1), T + 1, dtype=torch.uint8, **kw)
         self.out_len = torch.zeros(max(N, 1), dtype=torch.int32, **kw)
         self.out_score = torch.zeros(max(N, 1), dtype=torch.float64, **kw)
-        self.ptrs = _lib.BeamStatePtrs(self.score.data_ptr(), self.lmsum.data_ptr(), self.ctx.data_ptr(),
-                                       self.hist.data_ptr(), self.node.data_ptr(), self.meta.data_ptr(),
+        self.ptrs = _lib.BeamStatePtrs(self.score.data_ptr(), self.lmsum.data_ptr(), self.lmsum_e.data_ptr(),
+                                       self.ctx.data_ptr(), self.hist.data_ptr(), self.ctx_id.data_ptr(),
+                                       self.ctxe_id.data_ptr(), self.node.data_ptr(), self.meta.data_ptr(),
                                        self.utt.data_ptr(), self.done_count.data_ptr())
         self.steps_run = 0
 
@@ -144,7 +153,8 @@ class NSDecoder:
         return Workspace(int(N), self.B, self.T, self.device, with_masks)
 
     def init(self, ws: Workspace) -> None:
-        _lib.check(self.L.nsd_state_init(C.byref(ws.ptrs), ws.N, ws.B, _stream_ptr()), "nsd_state_init")
+        _lib.check(self.L.nsd_state_init(self.tables.handle, C.byref(ws.ptrs), ws.N, ws.B, _stream_ptr()),
+                   "nsd_state_init")
         ws.steps_run = 0
 
     def step(self, ws: Workspace, logits: Optional[torch.Tensor] = None) -> None:

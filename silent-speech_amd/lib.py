@@ -30,8 +30,10 @@ class TrieCSR(C.Structure):
 
 
 class NgramHash(C.Structure):
-    _fields_ = [("order", C.c_int32), ("reserved", C.c_int32), ("gram_cap", C.c_uint64), ("ctx_cap", C.c_uint64),
-                ("grams", C.c_void_p), ("ctxs", C.c_void_p), ("unseen", C.c_double)]
+    _fields_ = [("order", C.c_int32), ("init_ctx", C.c_uint32), ("gram_cap", C.c_uint64), ("ctx_cap", C.c_uint64),
+                ("grams", C.c_void_p), ("ctxs", C.c_void_p), ("unseen", C.c_double),
+                ("n_ctx_recs", C.c_uint32), ("n_gram_recs", C.c_uint32), ("ctx_recs", C.c_void_p),
+                ("gram_recs", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -41,8 +43,9 @@ class Params(C.Structure):
 
 
 class BeamStatePtrs(C.Structure):
-    _fields_ = [("score", C.c_void_p), ("lmsum", C.c_void_p), ("ctx", C.c_void_p), ("hist", C.c_void_p),
-                ("node", C.c_void_p), ("meta", C.c_void_p), ("utt", C.c_void_p), ("done_count", C.c_void_p)]
+    _fields_ = [("score", C.c_void_p), ("lmsum", C.c_void_p), ("lmsum_e", C.c_void_p), ("ctx", C.c_void_p),
+                ("hist", C.c_void_p), ("ctx_id", C.c_void_p), ("ctxe_id", C.c_void_p), ("node", C.c_void_p),
+                ("meta", C.c_void_p), ("utt", C.c_void_p), ("done_count", C.c_void_p)]
 
 
 EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "nsd_tables_destroy",
@@ -70,7 +73,7 @@ def load():
     L.nsd_tables_create.argtypes = [C.POINTER(TrieCSR), C.POINTER(NgramHash), C.POINTER(vp)]
     L.nsd_tables_destroy.argtypes = [vp]
     L.nsd_tables_order.argtypes = [vp]
-    L.nsd_state_init.argtypes = [C.POINTER(BeamStatePtrs), i32, i32, vp]
+    L.nsd_state_init.argtypes = [vp, C.POINTER(BeamStatePtrs), i32, i32, vp]
     L.nsd_step.argtypes = [vp, C.POINTER(Params), vp, C.POINTER(BeamStatePtrs), C.POINTER(BeamStatePtrs),
                            vp, vp, vp, i32, i32, i32, vp]
     L.nsd_backtrace.argtypes = [C.POINTER(BeamStatePtrs), vp, vp, i32, i32, i32, vp, vp, vp, vp]

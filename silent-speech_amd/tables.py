@@ -22,7 +22,11 @@ KEY_EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 NODE_DTYPE = np.dtype([("mask", "<u8"), ("child_base", "<u4"), ("reserved", "<u4")])
 GRAM_DTYPE = np.dtype([("key", "<u8"), ("logp", "<f8")])
-CTX_DTYPE = np.dtype([("key", "<u8"), ("backoff", "<f8"), ("term", "<f8"), ("reserved", "<u8")])
+CTX_DTYPE = np.dtype([("key", "<u8"), ("backoff", "<f8"), ("term", "<f8"), ("ctx_id", "<u8")])
+CTXREC_DTYPE = np.dtype([("backoff", "<f8"), ("term", "<f8"), ("symmask", "<u8"), ("child_base", "<u4"),
+                         ("reserved", "<u4")])
+GRAMREC_DTYPE = np.dtype([("logp", "<f8"), ("term_next", "<f8"), ("next_ctx", "<u4"), ("reserved", "<u4")])
+CTX_NONE = 0xFFFFFFFF
 
 _CHILD_CHARS = BASE_CHARS[:36]
 _TOK = {c: i for i, c in enumerate(BASE_CHARS)}
@@ -80,6 +84,10 @@ def flatten_trie(trie) -> np.ndarray:
     from the root (scripts/ns_utils.py:235), so a literal space edge only
     sets the "space may follow" bit.
     """
+    if getattr(trie, "end", False) or " " in trie.next:
+        # the empty prefix as a word (or a word starting with a space) would let a space follow a space;
+        # the reference's loaders can never build such a trie (empty and unstripped words are dropped)
+        raise ValueError("the trie root must not be a word or have a space edge")
     order = [trie]
     masks: list[int] = []
     bases: list[int] = []
@@ -186,8 +194,10 @@ class NgramCounts:
 class NgramTables:
     """Flat hash tables of one CharNgramLM-like object."""
 
-    def __init__(self, order: int, grams: np.ndarray, ctxs: np.ndarray, unseen: float, vsz: int):
+    def __init__(self, order: int, grams: np.ndarray, ctxs: np.ndarray, unseen: float, vsz: int,
+                 ctx_recs: np.ndarray, gram_recs: np.ndarray, init_ctx: int):
         self.order, self.grams, self.ctxs, self.unseen, self.vsz = order, grams, ctxs, unseen, vsz
+        self.ctx_recs, self.gram_recs, self.init_ctx = ctx_recs, gram_recs, init_ctx
 
 
 def compile_ngram(lm, floor_vsz: Optional[bool] = None) -> NgramTables:
@@ -228,22 +238,62 @@ def compile_ngram(lm, floor_vsz: Optional[bool] = None) -> NgramTables:
         cb.append(log((0 + 1) / (C + vsz + 1)))
         ct.append(log((counts.get(ctx + "$", 0) + 1) / (C + vsz + 1)))
 
-    grams = np.zeros(_capacity(len(gk)), dtype=GRAM_DTYPE)
+    gkeys = np.array(gk, dtype=np.uint64)
+    gvals = np.array(gv, dtype=np.float64)
+    ckeys = np.array(ck, dtype=np.uint64)
+    cback = np.array(cb, dtype=np.float64)
+    cterm = np.array(ct, dtype=np.float64)
+    unseen = log((0 + 1) / (0 + vsz + 1))
+
+    # context automaton: contexts in ascending key order, each one's seen n-grams in ascending symbol order
+    corder = np.argsort(ckeys, kind="stable")
+    ckeys, cback, cterm = ckeys[corder], cback[corder], cterm[corder]
+    gorder = np.argsort(gkeys, kind="stable")            # (ctx << 6 | sym) ascending = grouped by ctx, then sym
+    gkeys, gvals = gkeys[gorder], gvals[gorder]
+    ctx_recs = np.zeros(len(ckeys), dtype=CTXREC_DTYPE)
+    ctx_recs["backoff"], ctx_recs["term"] = cback, cterm
+    gram_recs = np.zeros(len(gkeys), dtype=GRAMREC_DTYPE)
+    gram_recs["logp"] = gvals
+    if len(gkeys):
+        sym_mask = np.uint64((1 << (6 * (order - 1))) - 1) if order >= 2 else np.uint64(0)
+        gctx = gkeys >> np.uint64(6)
+        gsym = (gkeys & np.uint64(63)).astype(np.uint64)
+        owner = np.searchsorted(ckeys, gctx)
+        ok = (owner < len(ckeys))
+        ok[ok] = ckeys[owner[ok]] == gctx[ok]
+        if not ok.all():
+            raise ValueError("n-gram whose context is not in lm.context")
+        first = np.searchsorted(gctx, ckeys, side="left")
+        ctx_recs["child_base"] = first.astype(np.uint32)
+        np.bitwise_or.at(ctx_recs["symmask"], owner, np.uint64(1) << gsym)
+        nkeys = gkeys & sym_mask
+        nxt = np.searchsorted(ckeys, nkeys)
+        hit = nxt < len(ckeys)
+        hit[hit] = ckeys[nxt[hit]] == nkeys[hit]
+        gram_recs["next_ctx"] = np.where(hit, nxt, CTX_NONE).astype(np.uint32)
+        gram_recs["term_next"] = np.where(hit, cterm[np.minimum(nxt, len(ckeys) - 1)], unseen)
+    init_key = {1: 0, 2: SYM["^"]}.get(order)
+    init_ctx = CTX_NONE
+    if init_key is not None and len(ckeys):
+        j = int(np.searchsorted(ckeys, np.uint64(init_key)))
+        if j < len(ckeys) and int(ckeys[j]) == init_key:
+            init_ctx = j
+
+    grams = np.zeros(_capacity(len(gkeys)), dtype=GRAM_DTYPE)
     grams["key"] = KEY_EMPTY
-    if gk:
-        keys = np.array(gk, dtype=np.uint64)
-        s = _place(keys, grams.shape[0])
-        grams["key"][s] = keys
-        grams["logp"][s] = np.array(gv, dtype=np.float64)
-    ctxs = np.zeros(_capacity(len(ck)), dtype=CTX_DTYPE)
+    if len(gkeys):
+        sl = _place(gkeys, grams.shape[0])
+        grams["key"][sl] = gkeys
+        grams["logp"][sl] = gvals
+    ctxs = np.zeros(_capacity(len(ckeys)), dtype=CTX_DTYPE)
     ctxs["key"] = KEY_EMPTY
-    if ck:
-        keys = np.array(ck, dtype=np.uint64)
-        s = _place(keys, ctxs.shape[0])
-        ctxs["key"][s] = keys
-        ctxs["backoff"][s] = np.array(cb, dtype=np.float64)
-        ctxs["term"][s] = np.array(ct, dtype=np.float64)
-    return NgramTables(order, grams, ctxs, log((0 + 1) / (0 + vsz + 1)), vsz)
+    if len(ckeys):
+        sl = _place(ckeys, ctxs.shape[0])
+        ctxs["key"][sl] = ckeys
+        ctxs["backoff"][sl] = cback
+        ctxs["term"][sl] = cterm
+        ctxs["ctx_id"][sl] = np.arange(len(ckeys), dtype=np.uint64)
+    return NgramTables(order, grams, ctxs, unseen, vsz, ctx_recs, gram_recs, init_ctx)
 
 
 # ----------------------------------------------------------------------
@@ -296,3 +346,44 @@ def host_trie_walk(nodes: np.ndarray, word: str) -> int:
             return -1
         cur = int(nodes["child_base"][cur]) + bin(mask & ((1 << tok) - 1)).count("1")
     return cur
+
+
+def host_automaton_logp(t: NgramTables, text: str) -> float:
+    """Whole-string score by walking the context automaton (ctx_recs / gram_recs) the way nsd_step does,
+    falling back to the context hash on unseen transitions; same summation order as CharNgramLM.logp."""
+    if not text:
+        return -1e9
+    s = "^" + text.strip().lower() + "$"
+    n = t.order
+    syms = [SYM[c] for c in s]
+    total = 0.0
+    key, cid = 0, CTX_NONE
+    sym_mask = (1 << (6 * (n - 1))) - 1 if n >= 2 else 0
+
+    def find(k):
+        j = host_find(t.ctxs, k)
+        return int(t.ctxs["ctx_id"][j]) if j >= 0 else CTX_NONE
+
+    if n == 1:
+        cid = find(0)
+    for i, sym in enumerate(syms):
+        have = i                                   # symbols before this one
+        nxt_id = CTX_NONE
+        resolved = False
+        if have >= n - 1 and i + 1 >= n:           # the window ending at symbol i exists
+            if cid != CTX_NONE:
+                rec = t.ctx_recs[cid]
+                if (int(rec["symmask"]) >> sym) & 1:
+                    g = t.gram_recs[int(rec["child_base"]) + bin(int(rec["symmask"]) & ((1 << sym) - 1)).count("1")]
+                    total += float(g["logp"])
+                    nxt_id, resolved = int(g["next_ctx"]), True
+                else:
+                    total += float(rec["backoff"])
+            else:
+                total += t.unseen
+        key = ((key << 6) | sym) & sym_mask if n >= 2 else 0
+        if have + 1 >= n - 1:
+            cid = nxt_id if resolved else find(key)
+        else:
+            cid = CTX_NONE
+    return total

@@ -63,6 +63,7 @@ def test_ngram_tables_reproduce_logp_bit_exact(order, floor):
         if any(c not in T.SYM for c in text.strip().lower()):
             continue
         assert T.host_logp(t, text).hex() == lm.logp(text).hex(), (order, floor, text)
+        assert T.host_automaton_logp(t, text).hex() == lm.logp(text).hex(), (order, floor, text)
 
 
 def test_ngram_tables_empty_lm_probe():
@@ -109,8 +110,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from silent_speech_amd import lib
     assert ctypes.sizeof(lib.Params) == 4 * 4 + 4 * 8 + 8 * (128 + 4)
-    assert ctypes.sizeof(lib.BeamStatePtrs) == 8 * 8
-    assert ctypes.sizeof(lib.NgramHash) == 48
+    assert ctypes.sizeof(lib.BeamStatePtrs) == 11 * 8
+    assert ctypes.sizeof(lib.NgramHash) == 72
+    assert T.CTXREC_DTYPE.itemsize == 32 and T.GRAMREC_DTYPE.itemsize == 24
     assert T.NODE_DTYPE.itemsize == 16 and T.GRAM_DTYPE.itemsize == 16 and T.CTX_DTYPE.itemsize == 32
 
 
