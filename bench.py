@@ -131,7 +131,9 @@ def main():
     ap.add_argument("--open-lexicon", action="store_true", help="100k-word a-z0-9 lexicon (configs[2])")
     ap.add_argument("--corpus", type=int, default=20000)
     ap.add_argument("--seed", type=int, default=20260403)
-    ap.add_argument("--check-every", type=int, default=8)
+    ap.add_argument("--check-every", type=int, default=0,
+                    help="poll the done counter every this many steps (0 = enqueue all T_max steps)")
+    ap.add_argument("--event-every", type=int, default=4, help="time the nsd_step launches of every n-th decode")
     ap.add_argument("--cpu-utts", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -170,23 +172,17 @@ def main():
     n_total = args.utts * world
 
     use_events = not args.no_events
-    ev = []
+    step_ms = np.zeros(max(args.tmax, 1), np.float32)
+    durs = []                                   # per-launch nsd_step durations (ms) from HIP events
 
-    def one_decode(timed: bool):
-        dec.init(ws)
-        for t in range(dec.T):
-            dec.synth_logits(ws, args.seed, args.utt0, tgd, tld, args.margin)
-            if timed and use_events:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                dec.step(ws)
-                b.record()
-                ev.append((a, b))
-            else:
-                dec.step(ws)
-            if (t + 1) % args.check_every == 0 and dec.all_done(ws):
-                break
-        ids, lens, _ = dec.finish(ws)
+    def one_decode(timed: bool, k: int = 0):
+        # the whole step loop is enqueued by native code; on every `event_every`-th timed decode each
+        # nsd_step launch is bracketed by HIP events on the launch stream
+        sm = step_ms if (timed and use_events and k % args.event_every == 0) else None
+        ids, lens, _ = dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0,
+                                               check_every=args.check_every, ws=ws, step_ms=sm)
+        if sm is not None:
+            durs.append(sm[:ws.steps_run].copy())
         return gather_results(ids, lens, n_total, dst=0)
 
     def fence():
@@ -198,8 +194,8 @@ def main():
         one_decode(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_decode(True)
+    for k in range(args.steps):
+        out = one_decode(True, k)
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -208,8 +204,8 @@ def main():
     dt = float(tmax.item())
 
     # characters decoded by this rank (identical every repetition: the decode is deterministic)
-    ids_l, lens_l, _ = dec.finish(ws)
-    ids_np, lens_np = ids_l.cpu().numpy(), lens_l.cpu().numpy()
+    dec.raise_on_topk_error(ws)
+    ids_np, lens_np = ws.out_ids[:args.utts].cpu().numpy(), ws.out_len[:args.utts].cpu().numpy()
     from silent_speech_amd.decoder import ids_to_text
     from silent_speech_amd import TextTransform
     texts = [ids_to_text(TextTransform, ids_np[u, :lens_np[u]].tolist()) for u in range(args.utts)]
@@ -251,18 +247,25 @@ def main():
 
     # roofline of the dominant kernel (nsd_step): algorithmic bytes / measured launch duration
     T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, args)
+    if len(per_step) < ws.steps_run:            # launches after every utterance finished move no bytes
+        pad = ws.steps_run - len(per_step)
+        per_step = np.concatenate([per_step, np.zeros(pad, np.int64)])
+        live = np.concatenate([live, np.zeros(pad, np.int64)])
+        cands = np.concatenate([cands, np.zeros(pad, np.int64)])
     bytes_per_launch = float(per_step[:ws.steps_run].sum()) / max(ws.steps_run, 1)
-    if use_events and ev:
-        torch.cuda.synchronize()
-        durs = np.array([a.elapsed_time(b) for a, b in ev]) * 1e-3          # seconds
-        avg = float(durs.mean())
+    if use_events and durs:
+        d = np.concatenate(durs).astype(np.float64) * 1e-3                 # seconds
+        avg = float(d.mean())
         achieved = bytes_per_launch / avg / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                              "kernel": "nsd_step_kernel", "launches_timed": len(ev),
+                              "kernel": "nsd_step_kernel", "launches_timed": int(d.size),
                               "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
-                              "mean_live_hyps_per_launch": float(live[:ws.steps_run].mean()),
-                              "mean_children_per_live_hyp": float(cands.sum() / max(live.sum(), 1))}
+                              "mean_live_hyps_per_launch": float(live.sum() / max(ws.steps_run, 1)),
+                              "mean_children_per_live_hyp": float(cands.sum() / max(live.sum(), 1)),
+                              "busiest_launch": {"us": float(d.reshape(len(durs), -1).mean(0).max() * 1e6),
+                                                 "GBps": float((per_step[:ws.steps_run] /
+                                                                np.maximum(d.reshape(len(durs), -1).mean(0)[:len(per_step[:ws.steps_run])], 1e-9)).max() / 1e9)}}
     if not args.no_cpu and world == 1:
         result["cpu_baseline"] = cpu_baseline(words, corpus, targets, args, texts)
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()

@@ -253,6 +253,29 @@ int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int64_t utt0,
                      const int8_t *targets, const int32_t *target_len, int32_t stride,
                      float margin, float *logits, int32_t N, int32_t B, void *stream);
 
+/* The whole batched decode loop of inference_emg_llm.py:416-435 for the
+ * synthetic AR head, enqueued from native code: state init, then up to T
+ * rounds of { nsd_synth_logits, nsd_step }, then nsd_backtrace.
+ *   check_every > 0: every that many steps the done counter is copied to the
+ *                    host and the loop stops once all N utterances are done
+ *                    (one stream synchronisation per check); 0 = run all T
+ *                    steps (finished utterances cost an early-exit wave each)
+ *   step_ms   host [T] or NULL: when given, every nsd_step launch is bracketed
+ *             by HIP events on `stream` and its duration in milliseconds is
+ *             stored (entries of steps that did not run are set to -1); the
+ *             call then ends with one stream synchronisation
+ *   steps_run host [1] or NULL: number of steps enqueued
+ * Buffers as in the single calls: logits device [N*B, V], backptr/token
+ * device [T, N*B], out_ids device [N, T+1], out_len device [N], out_score
+ * device [N] or NULL. */
+int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const NsdBeamState *st,
+                     uint64_t base_seed, int64_t utt0,
+                     const int8_t *targets, const int32_t *target_len, int32_t stride, float margin,
+                     float *logits, uint8_t *backptr, uint8_t *token,
+                     int32_t T, int32_t N, int32_t B,
+                     uint8_t *out_ids, int32_t *out_len, double *out_score,
+                     int32_t check_every, float *step_ms, int32_t *steps_run, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

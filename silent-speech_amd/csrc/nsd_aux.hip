@@ -2,6 +2,8 @@
 // rerank gather, log-softmax and the synthetic logits generator (gfx950).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 #include "nsd_device.h"
 
 // ---------------------------------------------------------------------
@@ -453,4 +455,79 @@ extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int6
                        (hipStream_t)stream, *st, base_seed, (long long)utt0, targets, target_len, stride,
                        margin, logits, N, B);
     return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
+// native decode driver for the synthetic AR head
+// ---------------------------------------------------------------------
+namespace {
+std::mutex g_ev_mutex;
+std::vector<hipEvent_t> g_events;          // grown on demand, reused by every timed decode
+uint32_t *g_host_done = nullptr;           // pinned word for the done-counter poll
+
+int ensure_events(size_t n)
+{
+    while (g_events.size() < n) {
+        hipEvent_t e;
+        hipError_t err = hipEventCreate(&e);
+        if (err != hipSuccess) return (int)err;
+        g_events.push_back(e);
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const NsdBeamState *st,
+                                uint64_t base_seed, int64_t utt0,
+                                const int8_t *targets, const int32_t *target_len, int32_t stride, float margin,
+                                float *logits, uint8_t *backptr, uint8_t *token,
+                                int32_t T, int32_t N, int32_t B,
+                                uint8_t *out_ids, int32_t *out_len, double *out_score,
+                                int32_t check_every, float *step_ms, int32_t *steps_run, void *stream)
+{
+    if (T < 0 || T > NSD_MAX_STEPS) return NSD_E_SIZE;
+    if (steps_run) *steps_run = 0;
+    int rc = nsd_state_init(t, st, N, B, stream);
+    if (rc != 0 || N == 0) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t NB = (size_t)N * B;
+    std::unique_lock<std::mutex> lock(g_ev_mutex, std::defer_lock);
+    if (step_ms || check_every > 0) lock.lock();
+    if (step_ms) {
+        if ((rc = ensure_events(2 * (size_t)T)) != 0) return rc;
+        for (int i = 0; i < T; ++i) step_ms[i] = -1.0f;
+    }
+    if (check_every > 0 && !g_host_done) {
+        hipError_t e = hipHostMalloc((void **)&g_host_done, sizeof(uint32_t), hipHostMallocDefault);
+        if (e != hipSuccess) return (int)e;
+    }
+    int ran = 0;
+    for (int step = 0; step < T; ++step) {
+        rc = nsd_synth_logits(st, base_seed, utt0, targets, target_len, stride, margin, logits, N, B, stream);
+        if (rc != 0) return rc;
+        if (step_ms) (void)hipEventRecord(g_events[2 * step], s);
+        rc = nsd_step(t, p, logits, st, st, backptr + (size_t)step * NB, token + (size_t)step * NB, nullptr,
+                      N, B, NSD_V, stream);
+        if (rc != 0) return rc;
+        if (step_ms) (void)hipEventRecord(g_events[2 * step + 1], s);
+        ran = step + 1;
+        if (check_every > 0 && ran % check_every == 0 && ran < T) {
+            hipError_t e = hipMemcpyAsync(g_host_done, st->done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return (int)e;
+            if (*g_host_done >= (uint32_t)N) break;
+        }
+    }
+    if (steps_run) *steps_run = ran;
+    rc = nsd_backtrace(st, backptr, token, T, N, B, out_ids, out_len, out_score, stream);
+    if (rc != 0) return rc;
+    if (step_ms) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return (int)e;
+        for (int i = 0; i < ran; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]) == hipSuccess) step_ms[i] = ms;
+        }
+    }
+    return NSD_OK;
 }

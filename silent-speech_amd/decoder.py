@@ -221,7 +221,8 @@ class NSDecoder:
 
     def decode_synth(self, targets: torch.Tensor, target_len: torch.Tensor, *, base_seed: int, margin: float,
                      utt0: int = 0, check_every: int = 8, ws: Optional[Workspace] = None):
-        """Decode with the synthetic integer-hash AR head (int8 targets [N, S] on device)."""
+        """Decode with the synthetic integer-hash AR head (int8 targets [N, S] on device); the step loop is
+        driven from Python, one launch at a time (this is the form that can record lexicon masks)."""
         N = targets.shape[0]
         ws = ws or self.workspace(N)
         self.init(ws)
@@ -231,6 +232,30 @@ class NSDecoder:
             if check_every and (t + 1) % check_every == 0 and self.all_done(ws):
                 break
         return self.finish(ws)
+
+    def decode_synth_native(self, targets: torch.Tensor, target_len: torch.Tensor, *, base_seed: int,
+                            margin: float, utt0: int = 0, check_every: int = 0, ws: Optional[Workspace] = None,
+                            step_ms: Optional[np.ndarray] = None):
+        """The same decode with the whole step loop enqueued by native code (nsd_decode_synth).  ``step_ms``
+        (float32 [T], host) receives the HIP-event duration of every nsd_step launch."""
+        N = targets.shape[0]
+        ws = ws or self.workspace(N)
+        ran = C.c_int32(0)
+        if step_ms is not None and (step_ms.dtype != np.float32 or step_ms.shape[0] < self.T):
+            raise ValueError("step_ms must be float32 with at least max_new_tokens entries")
+        _lib.check(self.L.nsd_decode_synth(
+            self.tables.handle, C.byref(self.params), C.byref(ws.ptrs), base_seed, utt0, targets.data_ptr(),
+            target_len.data_ptr(), targets.shape[1], float(margin), ws.logits.data_ptr(), ws.backptr.data_ptr(),
+            ws.token.data_ptr(), ws.T, ws.N, ws.B, ws.out_ids.data_ptr(), ws.out_len.data_ptr(),
+            ws.out_score.data_ptr(), int(check_every), step_ms.ctypes.data if step_ms is not None else None,
+            C.byref(ran), _stream_ptr()), "nsd_decode_synth")
+        ws.steps_run = ran.value
+        return ws.out_ids[:ws.N], ws.out_len[:ws.N], ws.out_score[:ws.N]
+
+    def raise_on_topk_error(self, ws: Workspace) -> None:
+        if ws.N and bool((ws.utt[:ws.N] & _lib.U_ERR_TOPK).any().item()):
+            raise RuntimeError("selected index k out of range (beam larger than the vocabulary in the "
+                               "top-k fall-back)")
 
 
 # ----------------------------------------------------------------------

@@ -324,3 +324,30 @@ def test_gather_ids_matches_host_histories(dev):
                 assert list(ids[u, r, :lens[u, r]]) == hyps[u][r]
             else:
                 assert lens[u, r] == 0
+
+
+def test_native_decode_loop_equals_python_driven_loop(dev):
+    """nsd_decode_synth (whole loop enqueued by native code, with and without the done poll and the
+    per-launch events) gives the same ids, scores and back-pointers as the step-by-step calls."""
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    words = synth.make_lexicon(200, 0, max_len=8)
+    corpus = synth.make_sentences(words, 4000, 1)
+    targets = synth.make_sentences(words, 300, 7, 3, 7)
+    tg, tl = _pack_targets(targets)
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    for variant in ("U", "I", "E"):
+        lm = O.NgramLM(5, floor_vsz=(variant == "U")).fit(corpus)
+        dec = NSDecoder(DeviceTables.from_words(words, lm), 16, 48, variant=variant, lm_weight=0.05, word_bonus=0.35)
+        ws0 = dec.workspace(len(targets))
+        ids0, lens0, sc0 = dec.decode_synth(tgd, tld, base_seed=3, margin=30.0, ws=ws0, check_every=0)
+        for check_every, timed in ((0, False), (8, False), (0, True), (5, True)):
+            ws1 = dec.workspace(len(targets))
+            sm = np.zeros(48, np.float32) if timed else None
+            ids1, lens1, sc1 = dec.decode_synth_native(tgd, tld, base_seed=3, margin=30.0, ws=ws1,
+                                                       check_every=check_every, step_ms=sm)
+            torch.cuda.synchronize()
+            assert torch.equal(lens0, lens1) and torch.equal(ids0, ids1) and torch.equal(sc0, sc1)
+            n = ws1.steps_run
+            assert torch.equal(ws0.backptr[:n], ws1.backptr[:n]) and torch.equal(ws0.token[:n], ws1.token[:n])
+            if timed:
+                assert (sm[:n] > 0).all() and (sm[n:] == -1).all()
