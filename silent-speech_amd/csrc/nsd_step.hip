@@ -335,21 +335,85 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     nsd_wave_sync();
 
     // ---------------- phase 4: top-B by (key desc, emission order asc) ----------------
+    // Rank = number of keys that beat mine, counted over broadcast LDS reads.  With more than 64
+    // candidates a threshold tau with nsel <= #{key >= tau} <= 64 is found first by a ballot quickselect
+    // (pivot = a key inside the open interval still in play), the survivors are compacted and ranked.
     const int nsel = (int)C < B ? (int)C : B;
-    for (uint32_t base = 0; base < C; base += 64) {
-        const uint32_t i = base + lane;
-        const bool valid = i < C;
-        const double mk = valid ? L.cKey[i] : 0.0;
-        uint32_t rank = 0;
-#pragma unroll 4
-        for (uint32_t q = 0; q < C; ++q) rank += (L.cKey[q] > mk) ? 1u : 0u;
-        if (valid && rank < (uint32_t)nsel) L.sel[rank] = i;
-    }
-    nsd_wave_sync();
     {
+        double *sKey = reinterpret_cast<double *>(L.rowbuf);          // [64] compacted survivors
+        uint32_t *sIdx = reinterpret_cast<uint32_t *>(L.rowbuf) + 128; // [64]
+        const double *keys = L.cKey;
+        uint32_t F = C;
+        bool compacted = false, full_scan = false;
+        if (C > 64) {
+            double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
+            bool ok = false;
+            for (int it = 0; it < 40 && !ok; ++it) {
+                // pivot: first key in (lo, hi), starting at a lane that rotates with the iteration
+                bool have = false;
+                double pivot = 0.0;
+                for (uint32_t base = 0; base < C && !have; base += 64) {
+                    const uint32_t i = base + lane;
+                    const double k = i < C ? L.cKey[i] : 0.0;
+                    const uint64_t act = __ballot(i < C && k > lo && k < hi);
+                    if (act) {
+                        const int rot = (it * 23 + 11) & 63;
+                        const uint64_t hiPart = act & ~((1ull << rot) - 1ull);
+                        const int pl = __ffsll((long long)(hiPart ? hiPart : act)) - 1;
+                        const uint64_t kb = (uint64_t)__double_as_longlong(k);
+                        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, pl);
+                        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), pl);
+                        pivot = __longlong_as_double((long long)(((uint64_t)phi << 32) | plo));
+                        have = true;
+                    }
+                }
+                if (!have) break;
+                uint32_t c = 0;
+                for (uint32_t base = 0; base < C; base += 64) {
+                    const uint32_t i = base + lane;
+                    c += (uint32_t)__popcll(__ballot(i < C && L.cKey[i] >= pivot));
+                }
+                if (c < (uint32_t)nsel) hi = pivot;
+                else if (c > 64u) lo = pivot;
+                else { ok = true; tau = pivot; F = c; }
+            }
+            if (ok) {
+                uint32_t n = 0;
+                for (uint32_t base = 0; base < C; base += 64) {
+                    const uint32_t i = base + lane;
+                    const double k = i < C ? L.cKey[i] : 0.0;
+                    const bool pred = i < C && k >= tau;
+                    const uint64_t bal = __ballot(pred);
+                    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (pred) { sKey[n + pre] = k; sIdx[n + pre] = i; }
+                    n += (uint32_t)__popcll(bal);
+                }
+                nsd_wave_sync();
+                keys = sKey;
+                compacted = true;
+            } else {
+                full_scan = true;            // clustered / tied keys: exact pass over everything below
+            }
+        }
+        uint32_t claimed = (uint32_t)nsel;
+        if (!full_scan) {
+            const bool valid = (uint32_t)lane < F;
+            const double mk = valid ? keys[lane] : 0.0;
+            uint32_t rank = 0;
+#pragma unroll 4
+            for (uint32_t q = 0; q < F; ++q) rank += (keys[q] > mk) ? 1u : 0u;
+            const bool win = valid && rank < (uint32_t)nsel;
+            if (win) L.sel[rank] = compacted ? sIdx[lane] : (uint32_t)lane;
+            claimed = (uint32_t)__popcll(__ballot(win));
+        }
+        nsd_wave_sync();
+        // equal keys show up as a rank claimed twice: inside the top-B that leaves a hole, at its lower
+        // edge it makes more claimants than places
         const bool hole = lane < nsel && L.sel[lane] == SEL_NONE;
-        if (__ballot(hole) != 0) {
-            // exact ties among the keys: redo with the emission order as tie-break
+        if (full_scan || claimed != (uint32_t)nsel || __ballot(hole) != 0) {
+            // exact score ties (or no usable threshold): rank everything with the emission order as tie-break
+            if (lane < B) L.sel[lane] = SEL_NONE;
             nsd_wave_sync();
             for (uint32_t base = 0; base < C; base += 64) {
                 const uint32_t i = base + lane;

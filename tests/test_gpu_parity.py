@@ -351,3 +351,34 @@ def test_native_decode_loop_equals_python_driven_loop(dev):
             assert torch.equal(ws0.backptr[:n], ws1.backptr[:n]) and torch.equal(ws0.token[:n], ws1.token[:n])
             if timed:
                 assert (sm[:n] > 0).all() and (sm[n:] == -1).all()
+
+
+def test_exact_score_ties_follow_the_canonical_order(dev):
+    """Uniform logits and no LM make every candidate of a hypothesis tie exactly; pruning must then keep
+    the first candidates in emission order (parent rank, then token id), as a stable sort does."""
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    words = synth.make_lexicon(300, 2, max_len=5)
+    trie = O.build_trie(words)
+    for variant, B in (("I", 4), ("I", 16), ("U", 8), ("E", 16), ("I", 40)):
+        dec = NSDecoder(DeviceTables.from_words(words, None), B, 10, variant=variant, oov_penalty=1.0,
+                        word_bonus=0.0, min_len_for_eos=3)
+        ws = dec.workspace(3, with_masks=True)
+        dec.init(ws)
+        hyps = [[(0.0, [37], "")] for _ in range(3)]
+        for t in range(10):
+            dec.step(ws, torch.zeros(3 * B, 40, dtype=torch.float32, device=dev))
+            bp = ws.backptr[t].cpu().numpy().reshape(3, B)
+            tk = ws.token[t].cpu().numpy().reshape(3, B)
+            nb = ws.utt.cpu().numpy() & 0xFF
+            # the same step in the Python restatement, fed the same all-zero logits
+            trace = []
+            want = O.constrained_beam_decode(lambda ids: np.zeros(40, np.float32), O.TextTransformLike, B, t + 1,
+                                             trie, None, oov_penalty=1.0, variant=variant, word_bonus=0.0,
+                                             min_len_for_eos=3, log_softmax=O.lsm_det, trace=trace)
+            chosen = trace[-1]["chosen"] if len(trace) == t + 1 else None
+            if chosen is None:
+                break
+            for u in range(3):
+                assert nb[u] == len(chosen)
+                for r, (p, tok, sc) in enumerate(chosen):
+                    assert bp[u, r] == p and (tk[u, r] == (0xFF if tok < 0 else tok)), (variant, B, t, u, r)
