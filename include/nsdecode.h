@@ -150,6 +150,9 @@ typedef struct NsdParams {
     int32_t use_lm;                    /* lm is not None */
     int32_t allow_eos_anytime;         /* ns_utils.py:203 (variant U only) */
     int32_t min_len_for_eos;           /* eval_ar.py:226 (variant E only) */
+    int32_t lanes_per_utt;             /* 0 = choose from N and B; else 16, 32 or 64 (>= B): lanes of a wave
+                                          that work on one utterance (a tuning knob, results do not depend on it) */
+    int32_t reserved;
     double  beta;                      /* lm_weight   */
     double  gamma;                     /* oov_penalty */
     double  kappa;                     /* word_bonus  (variant E) */

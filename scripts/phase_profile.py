@@ -1,0 +1,53 @@
+"""Diagnostic: where does one nsd_step wave spend its cycles?
+
+Builds a separate library with -DNSD_STAMPS (lane 0 stores the shader clock at the phase boundaries into a
+buffer of its own), runs the benchmark decode step by step and prints the mean cycles per phase for chosen
+steps.  The stamps forbid overlaps the real kernel has: read the shares, not the totals.
+"""
+import subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np, torch
+from silent_speech_amd import build as B, lib
+
+so = ROOT / "gpurun_out" / "libnsdecode_stamps.so"
+so.parent.mkdir(exist_ok=True)
+cmd = [B.hipcc(), *B.FLAGS, "-DNSD_STAMPS", f"-I{ROOT/'include'}", f"-I{B.CSRC}", *[str(B.CSRC / s) for s in B.SOURCES], "-o", str(so)]
+subprocess.run(cmd, check=True)
+lib.SO_PATH = so
+from silent_speech_amd.decoder import DeviceTables, NSDecoder
+from silent_speech_amd import synthetic as S
+from silent_speech_amd.tables import NgramCounts
+import ctypes as C
+
+variant = sys.argv[1] if len(sys.argv) > 1 else "U"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+dev = torch.device("cuda", 0)
+words = S.make_lexicon(200, 0)
+lm = NgramCounts(5, floor_vsz=(variant == "U")).fit(S.make_sentences(words, 20000, 1))
+tg, tl = S.pack_targets(S.make_sentences(words, N, 1000, 3, 7))
+tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+dec = NSDecoder(DeviceTables.from_words(words, lm), 16, 64, variant=variant, lm_weight=0.05, word_bonus=0.35)
+ws = dec.workspace(N)
+stamps = torch.zeros(N, 8, dtype=torch.int64, device=dev)   # one row per wave (a wave carries 64/G utterances)
+L = lib.load()
+L.nsd_debug_set_stamps.argtypes = [C.c_void_p]
+assert L.nsd_debug_set_stamps(stamps.data_ptr()) == 0
+dec.init(ws)
+names = ["state+records", "passes(softmax,emit,score)", "carry", "select", "write"]
+for t in range(40):
+    dec.synth_logits(ws, 20260403, 0, tgd, tld, 60.0)
+    stamps.zero_()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); dec.step(ws); e1.record()
+    torch.cuda.synchronize()
+    if t in (0, 1, 2, 3, 5, 10, 20, 30, 39):
+        s = stamps.cpu().numpy()
+        act = s[:, 5] > 0
+        d = np.diff(s[act, :6], axis=1).astype(np.float64)
+        tot = (s[act, 5] - s[act, 0]).astype(np.float64)
+        span = (s[act, 5].max() - s[act, 0].min())
+        print(f"step {t:2d}: active waves {act.sum():5d}  kernel {e0.elapsed_time(e1)*1e3:6.1f} us  "
+              f"wave mean {tot.mean():8.0f} ticks  span {span} ticks | " + "  ".join(f"{n} {d[:,i].mean():7.0f}" for i, n in enumerate(names)))

@@ -1,19 +1,25 @@
 // nsd_step: one NS decode step for N utterances x B beams (gfx950).
 //
-// Work split: one 64-lane wave per utterance, no block-level barrier.
-//   phase 1  lane b loads hypothesis b's state, then (second dependent hop)
-//            its trie node record and its n-gram context record, into LDS
-//   phase 2  8 lanes per logits row (5 consecutive logits per lane), live rows
-//            only, 8 rows per pass: deterministic log-softmax, lexicon mask
-//            applied, the allowed (hypothesis, token) pairs are compacted into
-//            an LDS candidate list
-//   phase 3  one lane per listed candidate: one context-automaton record load
-//            (third hop), beta/gamma/kappa fusion, fp64 score and pruning key
-//   phase 4  top-B of the list: every lane counts, over broadcast LDS reads of
-//            all keys, how many beat its own candidate; that count is the rank
-//            (exact score ties take a slower pass that also compares the
-//            emission order)
-//   phase 5  lane r writes surviving hypothesis r: new score, n-gram state,
+// Work split: G lanes per utterance (G = 16, 32 or 64, the smallest >= B), so a
+// 64-lane wave carries 64/G utterances; every ballot, prefix sum and LDS region
+// is local to such a lane group and no block-level barrier is used.
+//   phase 1  lane b of a group loads hypothesis b's state, then (second
+//            dependent hop) its trie node record and its n-gram context
+//            record, into the group's LDS region
+//   passes   G/8 live logits rows per pass and utterance, 8 lanes per row
+//            (5 consecutive logits per lane): deterministic log-softmax,
+//            lexicon mask applied, the allowed (hypothesis, token) pairs are
+//            appended to the group's LDS candidate buffer and scored at once,
+//            one lane per new candidate: one context-automaton record load
+//            (third hop), beta/gamma/kappa fusion, fp64 score and pruning key.
+//            The buffer is bounded: when a pass might overflow it, the buffer
+//            is first pruned to its top-B (which cannot change the final top-B)
+//   select   top-B of the buffer: a ballot quickselect finds a threshold that
+//            leaves at most 2G candidates, then every lane counts over
+//            broadcast LDS reads how many survivors beat its own; that count
+//            is the rank (exact score ties take a slower pass that also
+//            compares the emission order)
+//   write    lane r writes surviving hypothesis r: new score, n-gram state,
 //            trie child, flags, history hash, back-pointer and token
 //
 // Restates the loop body of scripts/ns_utils.py:218-275 (variant U),
@@ -25,6 +31,15 @@ namespace {
 
 enum : uint32_t { K_CHAR = 0, K_EOS = 1, K_CARRY = 2, K_FALLBACK = 3 };
 constexpr uint32_t SEL_NONE = 0xFFFFFFFFu;
+
+#ifdef NSD_STAMPS
+// Diagnostic build only (never the shipped library): lane 0 of every wave stores the shader clock at the
+// phase boundaries into a buffer of its own that no other code reads.
+__device__ unsigned long long *g_nsd_stamps = nullptr;
+#define NSD_STAMP(k) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NSD_STAMP(k) do { } while (0)
+#endif
 
 // candidate info word: tok[0:6) kind[6:8) order[8:20) (= parent*64 + w)
 NSD_D uint32_t pack_info(uint32_t tok, uint32_t kind, uint32_t w, uint32_t parent)
@@ -40,24 +55,33 @@ struct StepArgs {
     uint8_t     *token;
     uint64_t    *mask_dbg;
     int32_t      N, B;
-    uint32_t     lds_per_wave;
-    uint32_t     maxc;
+    uint32_t     lds_per_utt;
+    uint32_t     cap;            // candidate buffer entries per utterance
 };
 
-struct WaveLds {
+struct GroupLds {
     double   *bScore, *bG, *bGe, *bBo, *bTermS;
     uint64_t *bCtx, *bHist, *bMask, *bSym;
-    uint32_t *bChild, *bLmBase, *bMeta, *bNode, *bCtxId, *bCtxeId, *live, *sel;
-    double   *cKey, *cScore;
-    uint32_t *cInfo;
+    uint32_t *bChild, *bLmBase, *bMeta, *bNode, *bCtxId, *bCtxeId, *live, *sel, *total;
+    double   *cKey, *cScore, *sKey;
+    uint32_t *cInfo, *sIdx;
     float    *rowbuf;
 };
 
 constexpr int BEAM_BYTES = 9 * 8 + 8 * 4;
 
-NSD_D WaveLds carve(unsigned char *base, int B, uint32_t maxc, bool with_score)
+NSD_HD uint32_t max_cands_per_beam(int B, int variant)
 {
-    WaveLds w;
+    const uint32_t kfb = (uint32_t)(B < NSD_V ? B : NSD_V);
+    const uint32_t lex = NSD_NBASE + (variant == NSD_VARIANT_I ? 0u : 1u);   // 37 characters (+ EOS)
+    const uint32_t fb = kfb + (variant == NSD_VARIANT_U ? 1u : 0u);
+    return lex > fb ? lex : fb;
+}
+
+template <int G>
+NSD_D GroupLds carve(unsigned char *base, int B, uint32_t cap, bool with_score)
+{
+    GroupLds w;
     unsigned char *p = base;
     w.bScore = (double *)p;   p += 8 * B;
     w.bG     = (double *)p;   p += 8 * B;
@@ -68,9 +92,11 @@ NSD_D WaveLds carve(unsigned char *base, int B, uint32_t maxc, bool with_score)
     w.bHist  = (uint64_t *)p; p += 8 * B;
     w.bMask  = (uint64_t *)p; p += 8 * B;
     w.bSym   = (uint64_t *)p; p += 8 * B;
-    w.cKey   = (double *)p;   p += 8 * (size_t)maxc;
-    w.cScore = (double *)p;   if (with_score) p += 8 * (size_t)maxc;
-    w.cInfo  = (uint32_t *)p; p += 4 * (size_t)maxc;
+    w.cKey   = (double *)p;   p += 8 * (size_t)cap;
+    w.cScore = (double *)p;   if (with_score) p += 8 * (size_t)cap;
+    w.sKey   = (double *)p;   p += 8 * 2 * G;
+    w.cInfo  = (uint32_t *)p; p += 4 * (size_t)cap;
+    w.sIdx   = (uint32_t *)p; p += 4 * 2 * G;
     w.bChild = (uint32_t *)p; p += 4 * B;
     w.bLmBase = (uint32_t *)p; p += 4 * B;
     w.bMeta  = (uint32_t *)p; p += 4 * B;
@@ -79,75 +105,104 @@ NSD_D WaveLds carve(unsigned char *base, int B, uint32_t maxc, bool with_score)
     w.bCtxeId = (uint32_t *)p; p += 4 * B;
     w.live   = (uint32_t *)p; p += 4 * B;
     w.sel    = (uint32_t *)p; p += 4 * B;
+    w.total  = (uint32_t *)p; p += 16;
     w.rowbuf = (float *)p;
     return w;
 }
 
-// most candidates one live hypothesis can emit (a carried, finished one emits exactly one)
-NSD_HD uint32_t max_cands_per_beam(int B, int variant)
-{
-    const uint32_t kfb = (uint32_t)(B < NSD_V ? B : NSD_V);
-    const uint32_t lex = NSD_NBASE + (variant == NSD_VARIANT_I ? 0u : 1u);   // 37 characters (+ EOS)
-    const uint32_t fb = kfb + (variant == NSD_VARIANT_U ? 1u : 0u);
-    return lex > fb ? lex : fb;
-}
-
 } // namespace
 
-static size_t nsd_step_lds_per_wave(int B, int variant, uint32_t *maxc_out)
+// Lanes per utterance.  A wave carries 64/G utterances: narrow groups cut the instructions per utterance
+// when few hypotheses are live, but serialise an utterance's rows over more passes, which only pays once
+// the launch has far more waves than the chip holds at a time.
+static int nsd_step_group(int B, int N, int hint)
 {
-    uint32_t maxc = (uint32_t)B * max_cands_per_beam(B, variant);
-    maxc = (maxc + 1u) & ~1u;
-    size_t bytes = (size_t)B * BEAM_BYTES + (size_t)maxc * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) + 8 * 40 * 4;
+    const int gmin = B <= 16 ? 16 : (B <= 32 ? 32 : 64);
+    if (hint == 16 || hint == 32 || hint == 64) return hint < gmin ? gmin : hint;
+    return N >= 16384 ? (gmin < 32 ? 32 : gmin) : 64;
+}
+
+static size_t nsd_step_lds_per_utt(int B, int G, int variant, uint32_t *cap_out)
+{
+    // room for a pruned buffer (B) plus the most one pass can add, and enough that ordinary steps
+    // (about 10 candidates per hypothesis) never prune before the final selection
+    uint32_t cap = (uint32_t)B + (uint32_t)(G / 8) * max_cands_per_beam(B, variant);
+    if (cap < 10u * (uint32_t)B) cap = 10u * (uint32_t)B;
+    if (cap < 6u * (uint32_t)G) cap = 6u * (uint32_t)G;
+    cap = (cap + 1u) & ~1u;
+    size_t bytes = (size_t)B * BEAM_BYTES + (size_t)cap * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) +
+                   (size_t)2 * G * 12 + (size_t)(G / 8) * NSD_V * 4 + 16;
     bytes = (bytes + 15) & ~(size_t)15;
-    if (maxc_out) *maxc_out = maxc;
+    if (cap_out) *cap_out = cap;
     return bytes;
 }
 
-template <int WAVES, int VARIANT>
-__global__ void __launch_bounds__(WAVES * 64)
+template <int G, int VARIANT>
+__global__ void __launch_bounds__(256)
 nsd_step_kernel(StepArgs a, NsdParams P)
 {
+    constexpr int UPW = 64 / G;                   // utterances per wave
+    constexpr int RPP = G / 8;                    // logits rows per pass and utterance
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    const int u = blockIdx.x * WAVES + wid;
-    if (u >= a.N) return;                       // waves are independent: no block barrier anywhere
-
+    const int g = lane / G;
+    const int gl = lane % G;
+    const int gshift = g * G;
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+    const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + wid;
+    const long long ull = wave_id * UPW + g;
     const int B = a.B;
-    const uint32_t um = a.in.utt[u];
+    bool act = ull < (long long)a.N;
+    const int u = act ? (int)ull : 0;
+    const uint32_t um = act ? a.in.utt[u] : NSD_U_DONE;
     const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
-    const bool aliased = a.in.score == a.out.score;
 
-    if (um & NSD_U_DONE) {
-        if (!aliased) {
-            if (lane < nbeams) {
-                const size_t i = (size_t)u * B + lane;
+    if (act && (um & NSD_U_DONE)) {
+        if (a.in.score != a.out.score) {
+            if (gl < nbeams) {
+                const size_t i = (size_t)u * B + gl;
                 a.out.score[i] = a.in.score[i]; a.out.lmsum[i] = a.in.lmsum[i]; a.out.lmsum_e[i] = a.in.lmsum_e[i];
                 a.out.ctx[i] = a.in.ctx[i];     a.out.hist[i] = a.in.hist[i];
                 a.out.ctx_id[i] = a.in.ctx_id[i]; a.out.ctxe_id[i] = a.in.ctxe_id[i];
                 a.out.node[i] = a.in.node[i];   a.out.meta[i] = a.in.meta[i];
             }
-            if (lane == 0) a.out.utt[u] = um;
+            if (gl == 0) a.out.utt[u] = um;
         }
-        return;
+        act = false;
     }
+    if (__ballot(act) == 0) return;               // every utterance of this wave is finished or out of range
+    NSD_STAMP(0);
+
+    auto gballot = [&](bool pred) -> uint64_t { return (__ballot(pred) >> gshift) & gmask; };
+    // maximum over the wave's groups of a value that is uniform inside each group (scalar result)
+    auto wave_max = [&](uint32_t v) -> uint32_t {
+        uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+#pragma unroll
+        for (int q = 1; q < UPW; ++q) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)v, q * G);
+            m = o > m ? o : m;
+        }
+        return m;
+    };
+    auto gprefix = [&](uint64_t gb) -> uint32_t { return (uint32_t)__popcll(gb & ((1ull << gl) - 1ull)); };
 
     const bool use_lm = P.use_lm != 0 && a.tab.order > 0;
     const int order = a.tab.order;
-    WaveLds L = carve(smem + (size_t)wid * a.lds_per_wave, B, a.maxc, VARIANT == NSD_VARIANT_E);
+    const uint32_t CAP = a.cap;
+    GroupLds L = carve<G>(smem + ((size_t)wid * UPW + g) * a.lds_per_utt, B, CAP, VARIANT == NSD_VARIANT_E);
 
     // ---------------- phase 1: hypothesis state -> LDS ----------------
     bool my_live = false;
-    if (lane < B) L.sel[lane] = SEL_NONE;
-    if (lane < nbeams) {
-        const size_t i = (size_t)u * B + lane;
+    if (gl == 0) L.total[0] = 0;
+    if (act && gl < nbeams) {
+        const size_t i = (size_t)u * B + gl;
         const uint32_t meta = a.in.meta[i];
         const uint32_t node = a.in.node[i];
         const uint32_t ctx_id = a.in.ctx_id[i];
         const uint32_t ctxe_id = a.in.ctxe_id[i];
         const double score = a.in.score[i];
-        const double G = a.in.lmsum[i];
+        const double G0 = a.in.lmsum[i];
         const double Ge = a.in.lmsum_e[i];
         const uint64_t ctx = a.in.ctx[i];
         const uint64_t hist = a.in.hist[i];
@@ -181,44 +236,272 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint64_t mask = nrec.x;
         const uint32_t child = (uint32_t)nrec.y;
         if ((mask & ((1ull << NSD_NBASE) - 1)) == 0) mask = 0;     // nothing lexicon-consistent: fall-back
-        L.bScore[lane] = score; L.bG[lane] = G; L.bGe[lane] = Ge; L.bBo[lane] = bo; L.bTermS[lane] = term_s;
-        L.bCtx[lane] = ctx; L.bHist[lane] = hist; L.bMask[lane] = mask; L.bSym[lane] = sym;
-        L.bChild[lane] = child; L.bLmBase[lane] = lmbase; L.bMeta[lane] = meta; L.bNode[lane] = node;
-        L.bCtxId[lane] = ctx_id; L.bCtxeId[lane] = ctxe_id;
+        L.bScore[gl] = score; L.bG[gl] = G0; L.bGe[gl] = Ge; L.bBo[gl] = bo; L.bTermS[gl] = term_s;
+        L.bCtx[gl] = ctx; L.bHist[gl] = hist; L.bMask[gl] = mask; L.bSym[gl] = sym;
+        L.bChild[gl] = child; L.bLmBase[gl] = lmbase; L.bMeta[gl] = meta; L.bNode[gl] = node;
+        L.bCtxId[gl] = ctx_id; L.bCtxeId[gl] = ctxe_id;
         if (a.mask_dbg) a.mask_dbg[i] = mask & ((1ull << NSD_NBASE) - 1);
+        // upper bound of what this hypothesis adds to the candidate buffer
+        uint32_t cnt = 1;                                          // carried unchanged
+        if (my_live) cnt = mask ? (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + 1u
+                                : (uint32_t)(B < NSD_V ? B : NSD_V) + 1u;
+        atomicAdd(L.total, cnt);
     }
-    const uint64_t live_mask = __ballot(my_live);
-    const int nlive = __popcll(live_mask);
-    if (my_live) {
-        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(live_mask >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)live_mask, 0u));
-        L.live[pre] = (uint32_t)lane;
-    }
+    const uint64_t live_gb = gballot(my_live);
+    const int nlive = __popcll(live_gb);
+    if (my_live) L.live[gprefix(live_gb)] = (uint32_t)gl;
     nsd_wave_sync();
+    NSD_STAMP(1);
 
-    // ---------------- phase 2: log-softmax + candidate list ----------------
-    uint32_t C = 0;                               // wave-uniform candidate count
+    uint32_t C = 0;                               // candidates in this utterance's buffer (uniform in the group)
     bool err_topk = false;
+
     auto emit = [&](bool pred, float lp, uint32_t info) {
-        const uint64_t bal = __ballot(pred);
-        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        const uint64_t gb = gballot(pred);
         if (pred) {
-            const uint32_t s = C + pre;
+            const uint32_t s = C + gprefix(gb);
             L.cInfo[s] = info;
             reinterpret_cast<float *>(L.cKey)[2 * s] = lp;
         }
-        C += (uint32_t)__popcll(bal);
+        C += (uint32_t)__popcll(gb);
     };
 
+    // score candidates [from, C) of this group, one lane each
+    auto score_new = [&](uint32_t from) {
+        const uint32_t rounds = wave_max(act && C > from ? (C - from + G - 1) / G : 0u);
+        for (uint32_t rd = 0; rd < rounds; ++rd) {
+            const uint32_t i = from + rd * G + gl;
+            if (!(act && i < C)) continue;
+            const uint32_t info = L.cInfo[i];
+            const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = info >> 14;
+            const double lp = (double)reinterpret_cast<const float *>(L.cKey)[2 * i];
+            const double sb = L.bScore[p];
+            const uint32_t meta = L.bMeta[p];
+            const int glen = (int)(meta >> 8);
+            double score;
+            int Lnew = glen + 1;
+            if (kind == K_CARRY) {
+                score = sb;
+                Lnew = glen > 1 ? glen : 1;
+            } else if (kind == K_FALLBACK) {
+                score = sb + (lp - P.gamma);
+            } else if (kind == K_EOS && VARIANT == NSD_VARIANT_U) {
+                score = sb + lp;
+            } else {
+                const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
+                const int ms = 1 + glen - pend;
+                const bool whole = (L.bMask[p] >> 37) & 1;
+                double add = lp;
+                if (kind == K_EOS || tok == NSD_SPACE) {
+                    // both score the stripped surface: logp(surf + " ") == logp(surf)
+                    double lg = L.bG[p];
+                    if (ms + 1 >= order) lg = lg + L.bTermS[p];
+                    if (kind == K_EOS) {                   // variant E boundary EOS (eval_ar.py:290-296)
+                        add -= P.eos_len_nudge * (double)glen;
+                        if (use_lm && glen > 0) add += P.beta * lg;
+                    } else {
+                        if (use_lm) add += P.beta * lg;
+                        if (!whole) add -= P.gamma;
+                        if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
+                    }
+                } else if (use_lm) {
+                    const uint64_t ctx = L.bCtx[p];
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p],
+                                                       L.bBo[p], tok + 1u);
+                    double lg = L.bGe[p];
+                    if (s.has_int) lg = lg + s.lint;
+                    if (s.full_new) lg = lg + s.term;
+                    add += P.beta * lg;
+                }
+                score = sb + add;
+            }
+            if (VARIANT == NSD_VARIANT_E) {
+                L.cScore[i] = score;
+                L.cKey[i] = score / P.len_denom[Lnew];
+            } else {
+                L.cKey[i] = score;
+            }
+        }
+    };
+
+    // top-`nsel` of candidates [0, C): afterwards L.sel[r] = buffer index of rank r (r < nsel), for the
+    // groups with `want`; every lane of the wave must call it
+    auto select_top = [&](bool want, int nsel) {
+        if (want && gl < B) L.sel[gl] = SEL_NONE;
+        const uint32_t chunks = wave_max(want ? (C + G - 1) / G : 0u);   // buffer chunks of G candidates
+        uint32_t F = want ? C : 0u;
+        const double *keys = L.cKey;
+        bool compacted = false, full_scan = false;
+        // ---- threshold: at most 2G survivors ----
+        if (__ballot(want && C > 2u * G) != 0) {
+            bool searching = want && C > 2u * G;
+            double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
+            bool ok = false;
+            for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
+                // pivot: first key inside (lo, hi), starting at a lane that rotates with the iteration
+                bool have = false;
+                double pivot = 0.0;
+                for (uint32_t ch = 0; ch < chunks && __ballot(searching && !have) != 0; ++ch) {
+                    const uint32_t i = ch * G + gl;
+                    const bool inb = searching && !have && i < C;
+                    const double k = inb ? L.cKey[i] : 0.0;
+                    const uint64_t gb = gballot(inb && k > lo && k < hi);
+                    const bool pick = gb != 0 && searching && !have;
+                    int src = lane;
+                    if (pick) {
+                        const int rot = (it * 7 + 3) % G;
+                        const uint64_t hiPart = gb & ~((1ull << rot) - 1ull);
+                        src = gshift + __ffsll((long long)(hiPart ? hiPart : gb)) - 1;
+                    }
+                    const double cand = __shfl(k, src);
+                    if (pick) { pivot = cand; have = true; }
+                }
+                uint32_t c = 0;
+                for (uint32_t ch = 0; ch < chunks; ++ch) {
+                    const uint32_t i = ch * G + gl;
+                    c += (uint32_t)__popcll(gballot(searching && have && i < C && L.cKey[i] >= pivot));
+                }
+                if (searching) {
+                    if (!have) { full_scan = true; searching = false; }       // clustered / tied keys
+                    else if (c < (uint32_t)nsel) hi = pivot;
+                    else if (c > 2u * G) lo = pivot;
+                    else { ok = true; tau = pivot; F = c; searching = false; }
+                }
+            }
+            if (searching) { full_scan = true; searching = false; }
+            // compact the survivors
+            uint32_t n = 0;
+            for (uint32_t ch = 0; ch < chunks; ++ch) {
+                const uint32_t i = ch * G + gl;
+                const double k = (ok && i < C) ? L.cKey[i] : 0.0;
+                const bool pred = ok && i < C && k >= tau;
+                const uint64_t gb = gballot(pred);
+                if (pred) { const uint32_t s = n + gprefix(gb); L.sKey[s] = k; L.sIdx[s] = i; }
+                n += (uint32_t)__popcll(gb);
+            }
+            nsd_wave_sync();
+            if (ok) { keys = L.sKey; compacted = true; }
+        }
+        // ---- rank among the F <= 2G survivors: two per lane ----
+        uint32_t claimed = 0;
+        {
+            const uint32_t f0 = (uint32_t)gl, f1 = (uint32_t)gl + G;
+            const bool run = want && !full_scan;
+            const bool v0 = run && f0 < F, v1 = run && f1 < F;
+            const double k0 = v0 ? keys[f0] : 0.0, k1 = v1 ? keys[f1] : 0.0;
+            uint32_t r0 = 0, r1 = 0;
+            const uint32_t Fmax = wave_max(run ? F : 0u);
+            if (Fmax <= (uint32_t)G) {
+                // one candidate per lane; reads past a group's F compare against that group's own stale
+                // buffer entries and are discarded by the q < F test
+#pragma unroll 4
+                for (uint32_t q = 0; q < Fmax; ++q) r0 += (q < F && keys[q] > k0) ? 1u : 0u;
+            } else {
+#pragma unroll 2
+                for (uint32_t q = 0; q < Fmax; ++q) {
+                    const double k = keys[q];
+                    r0 += (q < F && k > k0) ? 1u : 0u;
+                    r1 += (q < F && k > k1) ? 1u : 0u;
+                }
+            }
+            const bool w0 = v0 && r0 < (uint32_t)nsel, w1 = v1 && r1 < (uint32_t)nsel;
+            if (w0) L.sel[r0] = compacted ? L.sIdx[f0] : f0;
+            if (w1) L.sel[r1] = compacted ? L.sIdx[f1] : f1;
+            claimed = (uint32_t)__popcll(gballot(w0)) + (uint32_t)__popcll(gballot(w1));
+        }
+        nsd_wave_sync();
+        // equal keys show up as a rank claimed twice: inside the top-B that leaves a hole, at its lower
+        // edge it makes more claimants than places
+        const bool hole = want && gl < nsel && L.sel[gl] == SEL_NONE;
+        const bool redo = want && (full_scan || claimed != (uint32_t)nsel || gballot(hole) != 0);
+        if (__ballot(redo) != 0) {
+            if (redo && gl < B) L.sel[gl] = SEL_NONE;
+            nsd_wave_sync();
+            const uint32_t Cmax = wave_max(redo ? C : 0u);
+            for (uint32_t ch = 0; ch < chunks; ++ch) {
+                const uint32_t i = ch * G + gl;
+                const bool valid = redo && i < C;
+                const double mk = valid ? L.cKey[i] : 0.0;
+                const uint32_t mo = valid ? ((L.cInfo[i] >> 8) & 0xFFFu) : 0u;
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < Cmax; ++q) {
+                    if (redo && q < C) {
+                        const double k = L.cKey[q];
+                        const uint32_t o = (L.cInfo[q] >> 8) & 0xFFFu;
+                        rank += (k > mk || (k == mk && (o < mo || (o == mo && q < i)))) ? 1u : 0u;
+                    }
+                }
+                if (valid && rank < (uint32_t)nsel) L.sel[rank] = i;
+            }
+            nsd_wave_sync();
+        }
+    };
+
+    // prune the buffer of the groups with `over` to its top-B, moved to the front
+    auto prune = [&](bool over) {
+        const int keep = (int)C < B ? (int)C : B;
+        select_top(over, keep);
+        uint32_t info = 0;
+        double key = 0.0, sc = 0.0;
+        if (over && gl < keep) {
+            const uint32_t s = L.sel[gl];
+            info = L.cInfo[s]; key = L.cKey[s];
+            if (VARIANT == NSD_VARIANT_E) sc = L.cScore[s];
+        }
+        nsd_wave_sync();
+        if (over && gl < keep) {
+            L.cInfo[gl] = info; L.cKey[gl] = key;
+            if (VARIANT == NSD_VARIANT_E) L.cScore[gl] = sc;
+        }
+        if (over) C = (uint32_t)keep;
+        nsd_wave_sync();
+    };
+
+    // finished hypotheses compete unchanged (ns_utils.py:222-224); they are scored with the first pass
+    emit(act && gl < nbeams && !my_live, 0.0f, pack_info(0x3f, K_CARRY, 0, (uint32_t)gl));
+    // when everything the step can emit fits the buffer (the usual case) no pass needs an overflow check
+    const bool may_overflow = __ballot(act && L.total[0] > CAP) != 0;
+
+    // ---------------- passes: log-softmax, candidates, scores ----------------
     const int j = lane & 7;
-    for (int pass = 0; pass * 8 < nlive; ++pass) {
-        const int slot = pass * 8 + (lane >> 3);
-        const bool live = slot < nlive;
+    const int npass = act ? (nlive + RPP - 1) / RPP : 0;
+    const int npass_max = (int)wave_max((uint32_t)npass);
+    uint32_t scored = 0;                          // candidates [0, scored) already have their key
+    for (int pass = 0; pass < npass_max; ++pass) {
+        const int slot = pass * RPP + (gl >> 3);
+        const bool live = act && slot < nlive;
         const int r = live ? (int)L.live[slot] : 0;
         const uint32_t meta = L.bMeta[r];
         const uint64_t mask = live ? L.bMask[r] : 0;
         const int glen = (int)(meta >> 8);
+        const bool whole = (mask >> 37) & 1;
+        const bool pend = (meta & NSD_F_PENDING_SPACE) != 0;
+        const bool eos_u = live && VARIANT == NSD_VARIANT_U && P.allow_eos_anytime;
+        const bool eos_e = live && VARIANT == NSD_VARIANT_E && mask != 0 &&
+                           glen >= P.min_len_for_eos && (pend || whole);
+        const bool fb = live && mask == 0 && !eos_e;
+        int kfb = B;
+        if (kfb > NSD_V) { kfb = NSD_V; if (VARIANT != NSD_VARIANT_U && fb) err_topk = true; }
+
+        // the buffer must hold what this pass can add; otherwise prune it to its top-B first
+        if (may_overflow) {
+            uint32_t add = 0;
+            if (live && j == 0)
+                add = fb ? (uint32_t)kfb + (eos_u ? 1u : 0u)
+                         : (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + ((eos_u || eos_e) ? 1u : 0u);
+#pragma unroll
+            for (int off = 8; off < G; off <<= 1) add += __shfl_xor(add, off);
+            add = __shfl(add, gshift);
+            const bool over = act && C + add > CAP;
+            if (__ballot(over) != 0) {
+                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored); nsd_wave_sync(); }
+                scored = C;
+                prune(over);
+                if (over) scored = C;
+            }
+        }
+
         float x[5];
         if (live) {
             const float *row = a.logits + ((size_t)u * B + r) * NSD_V + j * 5;
@@ -230,11 +513,6 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
         nsd_row_log_softmax5(x);
 
-        const bool whole = (mask >> 37) & 1;
-        const bool pend = (meta & NSD_F_PENDING_SPACE) != 0;
-        const bool eos_u = live && VARIANT == NSD_VARIANT_U && P.allow_eos_anytime;
-        const bool eos_e = live && VARIANT == NSD_VARIANT_E && mask != 0 &&
-                           glen >= P.min_len_for_eos && (pend || whole);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const uint32_t v = (uint32_t)(j * 5 + k);
@@ -247,15 +525,11 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
 
         // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
-        const bool fb = live && mask == 0 && !eos_e;
         if (__ballot(fb) != 0) {
-            float *rb = L.rowbuf + (lane >> 3) * NSD_V;
+            float *rb = L.rowbuf + (gl >> 3) * NSD_V;
 #pragma unroll
             for (int k = 0; k < 5; ++k) rb[j * 5 + k] = x[k];
             nsd_wave_sync();
-            int kfb = B;
-            if (VARIANT == NSD_VARIANT_U) { if (kfb > NSD_V) kfb = NSD_V; }
-            else if (kfb > NSD_V) { kfb = NSD_V; if (fb) err_topk = true; }
             uint32_t rank[5] = {0, 0, 0, 0, 0};
 #pragma unroll 1
             for (int i = 0; i < NSD_V; ++i) {
@@ -270,172 +544,24 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 const uint32_t w = rank[k] + (VARIANT == NSD_VARIANT_U ? 1u : 0u);
                 emit(fb && rank[k] < (uint32_t)kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)r));
             }
-            nsd_wave_sync();
-        }
-    }
-    {   // finished hypotheses compete unchanged (ns_utils.py:222-224)
-        const bool carry = lane < nbeams && !my_live;
-        emit(carry, 0.0f, pack_info(0x3f, K_CARRY, 0, (uint32_t)lane));
-    }
-    nsd_wave_sync();
-
-    // ---------------- phase 3: score every candidate ----------------
-    for (uint32_t i = lane; i < C; i += 64) {
-        const uint32_t info = L.cInfo[i];
-        const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = info >> 14;
-        const double lp = (double)reinterpret_cast<const float *>(L.cKey)[2 * i];
-        const double sb = L.bScore[p];
-        const uint32_t meta = L.bMeta[p];
-        const int glen = (int)(meta >> 8);
-        double score;
-        int Lnew = glen + 1;
-        if (kind == K_CARRY) {
-            score = sb;
-            Lnew = glen > 1 ? glen : 1;
-        } else if (kind == K_FALLBACK) {
-            score = sb + (lp - P.gamma);
-        } else if (kind == K_EOS && VARIANT == NSD_VARIANT_U) {
-            score = sb + lp;
-        } else {
-            const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
-            const int ms = 1 + glen - pend;
-            const bool whole = (L.bMask[p] >> 37) & 1;
-            double add = lp;
-            if (kind == K_EOS || tok == NSD_SPACE) {
-                // both score the stripped surface: logp(surf + " ") == logp(surf)
-                double lg = L.bG[p];
-                if (ms + 1 >= order) lg = lg + L.bTermS[p];
-                if (kind == K_EOS) {                   // variant E boundary EOS (eval_ar.py:290-296)
-                    add -= P.eos_len_nudge * (double)glen;
-                    if (use_lm && glen > 0) add += P.beta * lg;
-                } else {
-                    if (use_lm) add += P.beta * lg;
-                    if (!whole) add -= P.gamma;
-                    if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
-                }
-            } else if (use_lm) {
-                const uint64_t ctx = L.bCtx[p];
-                const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p],
-                                                   L.bBo[p], tok + 1u);
-                double lg = L.bGe[p];
-                if (s.has_int) lg = lg + s.lint;
-                if (s.full_new) lg = lg + s.term;
-                add += P.beta * lg;
-            }
-            score = sb + add;
-        }
-        if (VARIANT == NSD_VARIANT_E) {
-            L.cScore[i] = score;
-            L.cKey[i] = score / P.len_denom[Lnew];
-        } else {
-            L.cKey[i] = score;
-        }
-    }
-    nsd_wave_sync();
-
-    // ---------------- phase 4: top-B by (key desc, emission order asc) ----------------
-    // Rank = number of keys that beat mine, counted over broadcast LDS reads.  With more than 64
-    // candidates a threshold tau with nsel <= #{key >= tau} <= 64 is found first by a ballot quickselect
-    // (pivot = a key inside the open interval still in play), the survivors are compacted and ranked.
-    const int nsel = (int)C < B ? (int)C : B;
-    {
-        double *sKey = reinterpret_cast<double *>(L.rowbuf);          // [64] compacted survivors
-        uint32_t *sIdx = reinterpret_cast<uint32_t *>(L.rowbuf) + 128; // [64]
-        const double *keys = L.cKey;
-        uint32_t F = C;
-        bool compacted = false, full_scan = false;
-        if (C > 64) {
-            double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
-            bool ok = false;
-            for (int it = 0; it < 40 && !ok; ++it) {
-                // pivot: first key in (lo, hi), starting at a lane that rotates with the iteration
-                bool have = false;
-                double pivot = 0.0;
-                for (uint32_t base = 0; base < C && !have; base += 64) {
-                    const uint32_t i = base + lane;
-                    const double k = i < C ? L.cKey[i] : 0.0;
-                    const uint64_t act = __ballot(i < C && k > lo && k < hi);
-                    if (act) {
-                        const int rot = (it * 23 + 11) & 63;
-                        const uint64_t hiPart = act & ~((1ull << rot) - 1ull);
-                        const int pl = __ffsll((long long)(hiPart ? hiPart : act)) - 1;
-                        const uint64_t kb = (uint64_t)__double_as_longlong(k);
-                        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, pl);
-                        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), pl);
-                        pivot = __longlong_as_double((long long)(((uint64_t)phi << 32) | plo));
-                        have = true;
-                    }
-                }
-                if (!have) break;
-                uint32_t c = 0;
-                for (uint32_t base = 0; base < C; base += 64) {
-                    const uint32_t i = base + lane;
-                    c += (uint32_t)__popcll(__ballot(i < C && L.cKey[i] >= pivot));
-                }
-                if (c < (uint32_t)nsel) hi = pivot;
-                else if (c > 64u) lo = pivot;
-                else { ok = true; tau = pivot; F = c; }
-            }
-            if (ok) {
-                uint32_t n = 0;
-                for (uint32_t base = 0; base < C; base += 64) {
-                    const uint32_t i = base + lane;
-                    const double k = i < C ? L.cKey[i] : 0.0;
-                    const bool pred = i < C && k >= tau;
-                    const uint64_t bal = __ballot(pred);
-                    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (pred) { sKey[n + pre] = k; sIdx[n + pre] = i; }
-                    n += (uint32_t)__popcll(bal);
-                }
-                nsd_wave_sync();
-                keys = sKey;
-                compacted = true;
-            } else {
-                full_scan = true;            // clustered / tied keys: exact pass over everything below
-            }
-        }
-        uint32_t claimed = (uint32_t)nsel;
-        if (!full_scan) {
-            const bool valid = (uint32_t)lane < F;
-            const double mk = valid ? keys[lane] : 0.0;
-            uint32_t rank = 0;
-#pragma unroll 4
-            for (uint32_t q = 0; q < F; ++q) rank += (keys[q] > mk) ? 1u : 0u;
-            const bool win = valid && rank < (uint32_t)nsel;
-            if (win) L.sel[rank] = compacted ? sIdx[lane] : (uint32_t)lane;
-            claimed = (uint32_t)__popcll(__ballot(win));
         }
         nsd_wave_sync();
-        // equal keys show up as a rank claimed twice: inside the top-B that leaves a hole, at its lower
-        // edge it makes more claimants than places
-        const bool hole = lane < nsel && L.sel[lane] == SEL_NONE;
-        if (full_scan || claimed != (uint32_t)nsel || __ballot(hole) != 0) {
-            // exact score ties (or no usable threshold): rank everything with the emission order as tie-break
-            if (lane < B) L.sel[lane] = SEL_NONE;
-            nsd_wave_sync();
-            for (uint32_t base = 0; base < C; base += 64) {
-                const uint32_t i = base + lane;
-                const bool valid = i < C;
-                const double mk = valid ? L.cKey[i] : 0.0;
-                const uint32_t mo = valid ? ((L.cInfo[i] >> 8) & 0xFFFu) : 0u;
-                uint32_t rank = 0;
-                for (uint32_t q = 0; q < C; ++q) {
-                    const double k = L.cKey[q];
-                    const uint32_t o = (L.cInfo[q] >> 8) & 0xFFFu;
-                    rank += (k > mk || (k == mk && (o < mo || (o == mo && q < i)))) ? 1u : 0u;
-                }
-                if (valid && rank < (uint32_t)nsel) L.sel[rank] = i;
-            }
-            nsd_wave_sync();
-        }
+        score_new(scored);
+        scored = C;
+        nsd_wave_sync();
     }
+    NSD_STAMP(2);
+    NSD_STAMP(3);
 
-    // ---------------- phase 5: write the surviving hypotheses ----------------
+    // ---------------- final selection ----------------
+    const int nsel = (int)C < B ? (int)C : B;
+    select_top(act, nsel);
+    NSD_STAMP(4);
+
+    // ---------------- write the surviving hypotheses ----------------
     bool fin = true;
-    if (lane < nsel) {
-        uint32_t mysel = L.sel[lane];
+    if (act && gl < nsel) {
+        uint32_t mysel = L.sel[gl];
         if (mysel >= C) mysel = 0;                 // only reachable with NaN keys
         const uint32_t info = L.cInfo[mysel];
         const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = (info >> 14) & 0x3f;
@@ -443,7 +569,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint32_t meta = L.bMeta[p];
         uint32_t flags = meta & 0xffu;
         int glen = (int)(meta >> 8);
-        double G = L.bG[p], Ge = L.bGe[p];
+        double G0 = L.bG[p], Ge = L.bGe[p];
         uint64_t ctx = L.bCtx[p];
         uint64_t hist = L.bHist[p];
         uint32_t node = L.bNode[p];
@@ -466,7 +592,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 if (use_lm) {
                     const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctx, ctx_id, L.bSym[p], L.bLmBase[p],
                                                        L.bBo[p], NSD_SPACE + 1u);
-                    Ge = s.has_int ? G + s.lint : G;
+                    Ge = s.has_int ? G0 + s.lint : G0;
                     ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
                 }
                 flags |= NSD_F_PENDING_SPACE;
@@ -476,8 +602,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                     const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
                     const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, ctxe_id, L.bSym[p], L.bLmBase[p],
                                                        L.bBo[p], tok + 1u);
-                    G = s.has_int ? Ge + s.lint : Ge;
-                    Ge = G;
+                    G0 = s.has_int ? Ge + s.lint : Ge;
+                    Ge = G0;
                     ctx = s.ctxn;
                     ctx_id = ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
                 }
@@ -489,34 +615,55 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
         meta = flags | ((uint32_t)glen << 8);
         fin = (flags & NSD_F_FINISHED) != 0;
-        const size_t o = (size_t)u * B + lane;
-        a.out.score[o] = score; a.out.lmsum[o] = G; a.out.lmsum_e[o] = Ge; a.out.ctx[o] = ctx; a.out.hist[o] = hist;
+        const size_t o = (size_t)u * B + gl;
+        a.out.score[o] = score; a.out.lmsum[o] = G0; a.out.lmsum_e[o] = Ge; a.out.ctx[o] = ctx; a.out.hist[o] = hist;
         a.out.ctx_id[o] = ctx_id; a.out.ctxe_id[o] = ctxe_id;
         a.out.node[o] = node;   a.out.meta[o] = meta;
         a.backptr[o] = (uint8_t)p;
         a.token[o] = out_tok;
     }
-    const bool all_fin = __ballot(!fin) == 0;
-    const bool any_err = __ballot(err_topk) != 0;
-    if (lane == 0) {
+    const bool all_fin = gballot(!fin) == 0;
+    const bool any_err = gballot(err_topk) != 0;
+    if (act && gl == 0) {
         uint32_t nu = (uint32_t)nsel | (((um >> NSD_U_STEPS_SHIFT) + 1u) << NSD_U_STEPS_SHIFT) | (um & NSD_U_ERR_TOPK);
         if (all_fin) nu |= NSD_U_DONE;
         if (any_err) nu |= NSD_U_ERR_TOPK;
         a.out.utt[u] = nu;
         if (all_fin && a.out.done_count) atomicAdd(a.out.done_count, 1u);
     }
+    NSD_STAMP(5);
+}
+
+#ifdef NSD_STAMPS
+extern "C" int nsd_debug_set_stamps(unsigned long long *p)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nsd_stamps), &p, sizeof(p));
+}
+#endif
+
+template <int G, int VARIANT>
+static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s)
+{
+    constexpr int UPW = 64 / G;
+    const uint32_t lds_per_wave = a.lds_per_utt * UPW;
+    // waves per workgroup: 4 unless that needs more than 40 KiB of LDS (4 workgroups per CU)
+    int waves = 4;
+    while (waves > 1 && lds_per_wave * (uint32_t)waves > 40960u) waves >>= 1;
+    const long long n_waves = ((long long)N + UPW - 1) / UPW;
+    const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
+    hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves), lds_per_wave * (uint32_t)waves, s, a, p);
 }
 
 template <int VARIANT>
-static void launch_variant(const StepArgs &a, const NsdParams &p, int N, hipStream_t s)
+static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s)
 {
-    // waves per workgroup: as many as keep a workgroup's LDS at or under 40 KiB (4 workgroups per CU)
-    if (a.lds_per_wave * 4u <= 40960u)
-        hipLaunchKernelGGL((nsd_step_kernel<4, VARIANT>), dim3((N + 3) / 4), dim3(256), a.lds_per_wave * 4u, s, a, p);
-    else if (a.lds_per_wave * 2u <= 40960u)
-        hipLaunchKernelGGL((nsd_step_kernel<2, VARIANT>), dim3((N + 1) / 2), dim3(128), a.lds_per_wave * 2u, s, a, p);
-    else
-        hipLaunchKernelGGL((nsd_step_kernel<1, VARIANT>), dim3(N), dim3(64), a.lds_per_wave, s, a, p);
+    const int G = nsd_step_group(a.B, N, p.lanes_per_utt);
+    a.lds_per_utt = (uint32_t)nsd_step_lds_per_utt(a.B, G, p.variant, &a.cap);
+    switch (G) {
+    case 16: launch_gv<16, VARIANT>(a, p, N, s); break;
+    case 32: launch_gv<32, VARIANT>(a, p, N, s); break;
+    default: launch_gv<64, VARIANT>(a, p, N, s); break;
+    }
 }
 
 extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
@@ -535,7 +682,6 @@ extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *log
     a.tab = *t; a.logits = logits; a.in = *in; a.out = *out;
     a.backptr = backptr; a.token = token; a.mask_dbg = mask_dbg;
     a.N = N; a.B = B;
-    a.lds_per_wave = (uint32_t)nsd_step_lds_per_wave(B, p->variant, &a.maxc);
     hipStream_t s = (hipStream_t)stream;
     switch (p->variant) {
     case NSD_VARIANT_U: launch_variant<NSD_VARIANT_U>(a, *p, N, s); break;

@@ -109,7 +109,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from silent_speech_amd import lib
-    assert ctypes.sizeof(lib.Params) == 4 * 4 + 4 * 8 + 8 * (128 + 4)
+    assert ctypes.sizeof(lib.Params) == 6 * 4 + 4 * 8 + 8 * (128 + 4)
     assert ctypes.sizeof(lib.BeamStatePtrs) == 11 * 8
     assert ctypes.sizeof(lib.NgramHash) == 72
     assert T.CTXREC_DTYPE.itemsize == 32 and T.GRAMREC_DTYPE.itemsize == 24
