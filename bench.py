@@ -113,6 +113,11 @@ def cpu_baseline(words, corpus, targets, args, gpu_texts):
             "transcript_mismatches_vs_gpu": mism}
 
 
+def default_workload(a) -> bool:
+    return (a.utts == 4096 and a.beam == 16 and a.tmax == 64 and a.variant == "U" and a.order == 5
+            and a.lex_words == 200 and not a.open_lexicon and a.margin == 60.0 and a.beta == 0.05)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +271,15 @@ def main():
                               "busiest_launch": {"us": float(d.reshape(len(durs), -1).mean(0).max() * 1e6),
                                                  "GBps": float((per_step[:ws.steps_run] /
                                                                 np.maximum(d.reshape(len(durs), -1).mean(0)[:len(per_step[:ws.steps_run])], 1e-9)).max() / 1e9)}}
+    if "roofline" in result and default_workload(args):
+        # HBM bytes per nsd_step launch from separate rocprofv3 --pmc passes of this same command
+        # (profiles/r01_pmc_traffic.json, written by scripts/collect_traffic.py): 2 x FETCH_SIZE + WRITE_SIZE
+        try:
+            tr = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            result["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except Exception:
+            pass
     if not args.no_cpu and world == 1:
         result["cpu_baseline"] = cpu_baseline(words, corpus, targets, args, texts)
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()
