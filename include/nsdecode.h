@@ -238,6 +238,17 @@ int nsd_ctc_greedy(const float *logits, int32_t N, int32_t Tp, int32_t V,
 int nsd_lm_logp(const NsdTables *t, const uint8_t *text, const int32_t *len,
                 int32_t N, int32_t stride, double *out, void *stream);
 
+/* LM rerank of the AR hypothesis against the CTC proposal (inference_emg_llm.py:457-464, before
+ * postprocess): both id sequences are turned into text as ids_to_text does (skip BOS, stop at EOS, keep
+ * base characters, strip), scored with lm.logp(s) - 0.002 * len(s), and the maximum is taken with the AR
+ * hypothesis winning ties.
+ *   ar_ids  device [N, ar_stride] u8 starting with BOS, ar_len device [N] i32
+ *   ctc_ids device [N, ctc_stride] u8 collapsed CTC ids (no BOS/EOS), ctc_len device [N] i32
+ *   choice  device [N] u8: 0 = AR, 1 = CTC;  scores device [N, 2] f64 or NULL */
+int nsd_rerank_lm(const NsdTables *t, const uint8_t *ar_ids, const int32_t *ar_len, int32_t ar_stride,
+                  const uint8_t *ctc_ids, const int32_t *ctc_len, int32_t ctc_stride,
+                  int32_t N, uint8_t *choice, double *scores, void *stream);
+
 /* Teacher-forced sum of token log-probs (eval_ar.py:574-589):
  *   out[u] = sum_i log_softmax(logits[u, i, :])[target[u, i]], i < len[u]
  *   logits device [N, L, V] fp32; target device [N, L] u8; len device [N] i32 */

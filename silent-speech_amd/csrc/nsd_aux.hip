@@ -336,6 +336,76 @@ extern "C" int nsd_lm_logp(const NsdTables *t, const uint8_t *text, const int32_
     return (int)hipGetLastError();
 }
 
+// lm.logp(text) - 0.002 * len(text) of the text that ids_to_text would produce from `ids`
+// (scripts/ns_utils.py:284-296): optional leading BOS skipped, stop at EOS, ids >= 37 dropped, stripped
+__device__ double nsd_hyp_lm_score(const NsdTables &tab, const uint8_t *ids, int n, bool skip_first)
+{
+    // pass 1: bounds of the stripped text in the filtered character stream
+    int first = -1, last = -1, k = 0;
+    for (int i = skip_first ? 1 : 0; i < n; ++i) {
+        const uint8_t c = ids[i];
+        if (c == NSD_EOS) break;
+        if (c >= NSD_NBASE) continue;
+        if (c != NSD_SPACE) { if (first < 0) first = k; last = k; }
+        ++k;
+    }
+    if (k == 0) return -1e9;                       // empty string before strip: CharNgramLM returns -1e9
+    const int len = first < 0 ? 0 : last - first + 1;
+    // note: a text of spaces only is not empty for logp (it scores "^$"), but strip() makes len(s) = 0
+    // and ids_to_text has already stripped it, so logp sees "" -> -1e9
+    if (len == 0) return -1e9;
+    const int order = tab.order;
+    double lp = 0.0;
+    uint64_t ctx = 0;
+    int pos = 0;                                   // symbols consumed of '^' + text + '$'
+    auto feed = [&](uint32_t sym) {
+        if (pos + 1 >= order) {
+            double v;
+            if (!nsd_gram_find(tab, (ctx << 6) | sym, v)) v = nsd_ctx_backoff(tab, ctx);
+            lp += v;
+        }
+        ctx = nsd_ctx_shift(tab, ctx, sym);
+        ++pos;
+    };
+    feed(NSD_SYM_HAT);
+    k = 0;
+    for (int i = skip_first ? 1 : 0; i < n; ++i) {
+        const uint8_t c = ids[i];
+        if (c == NSD_EOS) break;
+        if (c >= NSD_NBASE) continue;
+        if (k >= first && k <= last) feed((uint32_t)c + 1u);
+        ++k;
+    }
+    feed(NSD_SYM_DOLLAR);
+    return lp - 0.002 * (double)len;
+}
+
+__global__ void nsd_rerank_lm_kernel(NsdTables tab, const uint8_t *ar_ids, const int32_t *ar_len, int ar_stride,
+                                     const uint8_t *ctc_ids, const int32_t *ctc_len, int ctc_stride,
+                                     int N, uint8_t *choice, double *scores)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= N) return;
+    const double sa = nsd_hyp_lm_score(tab, ar_ids + (size_t)u * ar_stride, ar_len[u], true);
+    const double sc = nsd_hyp_lm_score(tab, ctc_ids + (size_t)u * ctc_stride, ctc_len[u], false);
+    choice[u] = sc > sa ? 1 : 0;                   // max() keeps the first (AR) on ties
+    if (scores) { scores[2 * (size_t)u] = sa; scores[2 * (size_t)u + 1] = sc; }
+}
+
+extern "C" int nsd_rerank_lm(const NsdTables *t, const uint8_t *ar_ids, const int32_t *ar_len, int32_t ar_stride,
+                             const uint8_t *ctc_ids, const int32_t *ctc_len, int32_t ctc_stride,
+                             int32_t N, uint8_t *choice, double *scores, void *stream)
+{
+    if (!t) return NSD_E_NULL;
+    if (t->order < 1) return NSD_E_ORDER;
+    if (N < 0 || ar_stride < 0 || ctc_stride < 0) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!ar_ids || !ar_len || !ctc_ids || !ctc_len || !choice) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_rerank_lm_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       *t, ar_ids, ar_len, ar_stride, ctc_ids, ctc_len, ctc_stride, N, choice, scores);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------
 // log-softmax rows / rerank gather: 8 lanes per row
 // ---------------------------------------------------------------------

@@ -21,7 +21,7 @@ from .tables import (BASE_CHARS, BOS_ID, EOS_ID, PAD_ID, VOCAB, HostTrie, NgramT
                      flatten_trie)
 
 __all__ = ["DeviceTables", "NSDecoder", "Workspace", "constrained_beam_decode", "ids_to_text",
-           "ctc_greedy_batch", "lm_logp_batch", "rerank_gather_batch", "log_softmax_rows"]
+           "ctc_greedy_batch", "lm_logp_batch", "rerank_gather_batch", "log_softmax_rows", "rerank_lm_batch"]
 
 
 def _stream_ptr() -> int:
@@ -370,6 +370,20 @@ def lm_logp_batch(tables: DeviceTables, text_ids: torch.Tensor, lens: torch.Tens
     _lib.check(_lib.load().nsd_lm_logp(tables.handle, text_ids.data_ptr(), lens.data_ptr(), N, S,
                                        out.data_ptr(), _stream_ptr()), "nsd_lm_logp")
     return out[:N]
+
+
+def rerank_lm_batch(tables: DeviceTables, ar_ids: torch.Tensor, ar_len: torch.Tensor,
+                    ctc_ids: torch.Tensor, ctc_len: torch.Tensor):
+    """AR hypothesis vs CTC proposal by lm.logp(s) - 0.002*len(s) (inference_emg_llm.py:461-464, texts as
+    ids_to_text gives them, no postprocess): returns (choice u8 [N] with 1 = CTC, scores f64 [N, 2])."""
+    _require_cuda()
+    N = ar_ids.shape[0]
+    choice = torch.zeros(max(N, 1), dtype=torch.uint8, device=ar_ids.device)
+    scores = torch.zeros(max(N, 1), 2, dtype=torch.float64, device=ar_ids.device)
+    _lib.check(_lib.load().nsd_rerank_lm(tables.handle, ar_ids.data_ptr(), ar_len.data_ptr(), ar_ids.shape[1],
+                                         ctc_ids.data_ptr(), ctc_len.data_ptr(), ctc_ids.shape[1], N,
+                                         choice.data_ptr(), scores.data_ptr(), _stream_ptr()), "nsd_rerank_lm")
+    return choice[:N], scores[:N]
 
 
 def rerank_gather_batch(logits: torch.Tensor, target: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:

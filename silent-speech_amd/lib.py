@@ -52,7 +52,7 @@ class BeamStatePtrs(C.Structure):
 EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "nsd_tables_destroy",
            "nsd_tables_order", "nsd_state_init", "nsd_step", "nsd_backtrace", "nsd_gather_ids",
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
-           "nsd_decode_synth"]
+           "nsd_decode_synth", "nsd_rerank_lm"]
 
 _lib = None
 
@@ -87,6 +87,7 @@ def load():
     L.nsd_synth_logits.argtypes = [C.POINTER(BeamStatePtrs), u64, i64, vp, vp, i32, C.c_float, vp, i32, i32, vp]
     L.nsd_decode_synth.argtypes = [vp, C.POINTER(Params), C.POINTER(BeamStatePtrs), u64, i64, vp, vp, i32, C.c_float,
                                    vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.nsd_rerank_lm.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

@@ -382,3 +382,51 @@ def test_exact_score_ties_follow_the_canonical_order(dev):
                 assert nb[u] == len(chosen)
                 for r, (p, tok, sc) in enumerate(chosen):
                     assert bp[u, r] == p and (tk[u, r] == (0xFF if tok < 0 else tok)), (variant, B, t, u, r)
+
+
+def test_ctc_proposal_and_lm_rerank_pipeline(dev):
+    """BASELINE configs[3]: AR decode (variant I, as inference_emg_llm.py calls it) + CTC greedy proposal +
+    LM rerank, all on device, against the Python restatement of inference_emg_llm.py:436-464 without
+    postprocess."""
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder, ctc_greedy_batch, rerank_lm_batch
+    TT = O.TextTransformLike
+    words = synth.make_lexicon(200, 0, max_len=8)
+    corpus = synth.make_sentences(words, 4000, 1)
+    targets = synth.make_sentences(words, 257, 8, 2, 5)
+    tg, tl = _pack_targets(targets)
+    lm = O.NgramLM(3, floor_vsz=False).fit(corpus)
+    tables = DeviceTables.from_words(words, lm)
+    dec = NSDecoder(tables, 16, 24, variant="I", lm_weight=0.3, oov_penalty=1.0)
+    ar_ids, ar_len, _ = dec.decode_synth_native(torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev),
+                                                base_seed=4, margin=20.0)
+    # CTC logits: the target with frame repeats and blanks, a few corrupted frames, some empty proposals
+    rng = np.random.RandomState(9)
+    Tp = 96
+    x = rng.randn(len(targets), Tp, 40).astype(np.float32)
+    for u, t in enumerate(targets):
+        toks = synth.text_to_tokens(t)[: Tp // 4]
+        f = 0
+        for tok in toks:
+            x[u, f:f + 2, tok] += 8.0; x[u, f + 2, 39] += 8.0; f += 3
+        x[u, f:, 39] += 8.0
+        if u % 5 == 0:
+            x[u, rng.randint(0, max(f, 1)), rng.randint(0, 36)] += 20.0
+        if u % 17 == 0:
+            x[u] = 0.0; x[u, :, 39] = 5.0                      # empty CTC proposal
+        if u % 19 == 0:
+            x[u, :3, 36] += 30.0                               # leading spaces -> stripped
+    ctc_ids, ctc_len = ctc_greedy_batch(torch.from_numpy(x).to(dev))
+    choice, scores = rerank_lm_batch(tables, ar_ids, ar_len, ctc_ids, ctc_len)
+    ar_np, al = ar_ids.cpu().numpy(), ar_len.cpu().numpy()
+    choice, scores = choice.cpu().numpy(), scores.cpu().numpy()
+    n_ctc = 0
+    for u in range(len(targets)):
+        hyp_ar = O.ids_to_text(TT, ar_np[u, :al[u]].tolist())
+        hyp_ctc = O.ctc_hypothesis(x[u], TT)
+        want = O.rerank_lm(hyp_ar, hyp_ctc, lm)
+        got = hyp_ctc if choice[u] else hyp_ar
+        assert got == want, (u, hyp_ar, hyp_ctc)
+        assert float(scores[u, 0]).hex() == (float(lm.logp(hyp_ar)) - 0.002 * len(hyp_ar)).hex()
+        assert float(scores[u, 1]).hex() == (float(lm.logp(hyp_ctc)) - 0.002 * len(hyp_ctc)).hex()
+        n_ctc += int(choice[u])
+    assert 0 < n_ctc < len(targets)
