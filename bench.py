@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse "
+                                                             "several ranks on one GPU")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure throughput run)")
     args = ap.parse_args()
 
@@ -152,11 +154,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    if local >= ndev and args.dist_backend == "nccl":
+        raise SystemExit(f"LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local_dev = local % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
     from silent_speech_amd.dist import gather_results

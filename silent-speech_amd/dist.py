@@ -24,7 +24,7 @@ def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int
                    ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """Collect every rank's (ids u8 [n_r, T+1], lens i32 [n_r]) on `dst`, in utterance order.
 
-    One padded all_gather of each tensor (RCCL on GPUs, gloo on CPU); returns
+    One padded all_gather (RCCL on GPUs, gloo on CPU); returns
     (ids [n_total, T+1], lens [n_total]) on dst and None elsewhere.  Without an
     initialised process group the inputs are returned unchanged.
     """
@@ -33,15 +33,13 @@ def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_total + world - 1) // world
     width = ids.shape[1]
-    pad_ids = torch.zeros(per, width, dtype=ids.dtype, device=ids.device)
-    pad_len = torch.zeros(per, dtype=lens.dtype, device=lens.device)
     n = ids.shape[0]
-    pad_ids[:n] = ids
-    pad_len[:n] = lens
-    all_ids = torch.empty(world * per, width, dtype=ids.dtype, device=ids.device)
-    all_len = torch.empty(world * per, dtype=lens.dtype, device=lens.device)
-    dist.all_gather_into_tensor(all_ids, pad_ids)
-    dist.all_gather_into_tensor(all_len, pad_len)
+    # one collective: ids and the little-endian bytes of the int32 length travel in the same rows
+    pad = torch.zeros(per, width + 4, dtype=torch.uint8, device=ids.device)
+    pad[:n, :width] = ids
+    pad[:n, width:] = lens.to(torch.int32).contiguous().view(torch.uint8).reshape(n, 4)
+    out = torch.empty(world * per, width + 4, dtype=torch.uint8, device=ids.device)
+    dist.all_gather_into_tensor(out, pad)
     if rank != dst:
         return None
     keep: List[int] = []
@@ -49,4 +47,6 @@ def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int
         lo, hi = shard_range(n_total, r, world)
         keep.extend(range(r * per, r * per + (hi - lo)))
     idx = torch.tensor(keep, dtype=torch.long, device=ids.device)
-    return all_ids.index_select(0, idx), all_len.index_select(0, idx)
+    rows = out.index_select(0, idx)
+    all_len = rows[:, width:].clone().view(torch.int32).reshape(-1)      # clone: a fresh, 4-byte aligned storage
+    return rows[:, :width].contiguous(), all_len.to(lens.dtype)
