@@ -48,5 +48,7 @@ def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int
         keep.extend(range(r * per, r * per + (hi - lo)))
     idx = torch.tensor(keep, dtype=torch.long, device=ids.device)
     rows = out.index_select(0, idx)
-    all_len = rows[:, width:].clone().view(torch.int32).reshape(-1)      # clone: a fresh, 4-byte aligned storage
+    len_bytes = torch.empty(rows.shape[0], 4, dtype=torch.uint8, device=ids.device)   # fresh, aligned storage
+    len_bytes.copy_(rows[:, width:])
+    all_len = len_bytes.view(torch.int32).reshape(-1)
     return rows[:, :width].contiguous(), all_len.to(lens.dtype)
