@@ -9,10 +9,14 @@ gather of token ids.  Inputs (tables, planted targets) are resident in HBM
 before the timed region starts.
 
 Default workload (N = 1): BASELINE.json configs[1] - 4096 synthetic utterances,
-beam 16, closed 200-word template lexicon trie + character 5-gram LM, the
-ns_utils.py decoder (variant U), beta 0.05, gamma 1.0, planted-target margin
-60, T_max 64.  With --gpus N every rank decodes its own 4096-utterance shard
-(weak scaling) and rank 0 gathers the ids.
+beam 16, closed 200-word template lexicon trie + character 5-gram LM, decoded
+by the copy of the NS decoder that inference_emg_llm.py itself calls (variant
+I, inference_emg_llm.py:222-300: no EOS option, so every utterance runs all
+T_max = 64 steps with 16 live hypotheses), beta 0.05, gamma 1.0, planted-target
+margin 60.  The scripts/ns_utils.py copy (variant U, EOS offered at every
+step) is measured in the same run and reported under "variant_U".  With
+--gpus N every rank decodes its own 4096-utterance shard (weak scaling) and
+rank 0 gathers the ids.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -34,6 +38,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (spec)
+VARIANT_SRC = {"U": "scripts/ns_utils.py:194", "I": "inference_emg_llm.py:222", "E": "eval_ar.py:214"}
 
 
 def build_workload(n_utts: int, utt0: int, lex_words: int, corpus_n: int, order: int, open_lexicon: bool):
@@ -113,8 +118,50 @@ def cpu_baseline(words, corpus, targets, args, gpu_texts):
             "transcript_mismatches_vs_gpu": mism}
 
 
+def secondary_variant(args, variant, words, corpus, tgd, tld, targets):
+    """Same batch through another copy of the decoder: chars/s and the nsd_step roofline, briefly."""
+    import copy
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder, ids_to_text
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.tables import NgramCounts
+    a2 = copy.copy(args)
+    a2.variant = variant
+    lm = NgramCounts(args.order, floor_vsz=(variant == "U")).fit(corpus)
+    dec = NSDecoder(DeviceTables.from_words(words, lm), args.beam, args.tmax, variant=variant, lm_weight=args.beta,
+                    oov_penalty=args.gamma, word_bonus=args.kappa)
+    ws = dec.workspace(args.utts)
+    sm = np.zeros(max(args.tmax, 1), np.float32)
+    durs = []
+    reps = max(3, args.steps // 4)
+    for _ in range(2):
+        dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0, ws=ws)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        timed = (k % args.event_every == 0)
+        dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0, ws=ws,
+                                step_ms=sm if timed else None)
+        if timed:
+            durs.append(sm[:ws.steps_run].copy())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ids_np, lens_np = ws.out_ids[:args.utts].cpu().numpy(), ws.out_len[:args.utts].cpu().numpy()
+    texts = [ids_to_text(TextTransform, ids_np[u, :lens_np[u]].tolist()) for u in range(args.utts)]
+    chars = sum(len(t) for t in texts)
+    T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, a2)
+    steps_run = ws.steps_run
+    bytes_per_launch = float(per_step[:steps_run].sum()) / max(steps_run, 1)
+    d = np.concatenate(durs).astype(np.float64) * 1e-3
+    ach = bytes_per_launch / float(d.mean()) / 1e9
+    return {"source": VARIANT_SRC[variant], "value": chars * reps / dt, "unit": "chars/s", "decodes": reps,
+            "ms_per_decode": 1e3 * dt / reps, "chars_per_decode": chars,
+            "targets_recovered_exactly": sum(int(a == b) for a, b in zip(texts, targets)),
+            "roofline": {"achieved": ach, "frac": ach / HBM_PEAK_GBPS, "unit": "GB/s",
+                         "avg_launch_us": float(d.mean()) * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch}}
+
+
 def default_workload(a) -> bool:
-    return (a.utts == 4096 and a.beam == 16 and a.tmax == 64 and a.variant == "U" and a.order == 5
+    return (a.utts == 4096 and a.beam == 16 and a.tmax == 64 and a.variant == "I" and a.order == 5
             and a.lex_words == 200 and not a.open_lexicon and a.margin == 60.0 and a.beta == 0.05)
 
 
@@ -126,7 +173,8 @@ def main():
     ap.add_argument("--utts", type=int, default=4096, help="utterances per GPU")
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--tmax", type=int, default=64)
-    ap.add_argument("--variant", default="U", choices=["U", "I", "E"])
+    ap.add_argument("--variant", default="I", choices=["U", "I", "E"])
+    ap.add_argument("--also", default="U", help="second variant measured briefly in the same run ('' = none)")
     ap.add_argument("--order", type=int, default=5)
     ap.add_argument("--beta", type=float, default=0.05)
     ap.add_argument("--gamma", type=float, default=1.0)
@@ -251,7 +299,7 @@ def main():
         "config": {"workload": ("configs[2]: open 100k-word lexicon" if args.open_lexicon else
                                 "configs[1]: closed 200-word template lexicon") +
                                f", {args.utts} utterances per GPU, beam {args.beam}, char {args.order}-gram, "
-                               f"variant {args.variant} (scripts/ns_utils.py), beta {args.beta}, gamma {args.gamma}, "
+                               f"variant {args.variant} ({VARIANT_SRC[args.variant]}), beta {args.beta}, gamma {args.gamma}, "
                                f"margin {args.margin}, T_max {args.tmax}",
                    "utterances_total": n_total, "parallelism": f"utterance-sharded x{world}, replicated tables",
                    "chars_per_decode": float(chars.item()),
@@ -289,6 +337,8 @@ def main():
             result["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         except Exception:
             pass
+    if args.also and args.also != args.variant and world == 1:
+        result["variant_" + args.also] = secondary_variant(args, args.also, words, corpus, tgd, tld, targets)
     if not args.no_cpu and world == 1:
         result["cpu_baseline"] = cpu_baseline(words, corpus, targets, args, texts)
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()

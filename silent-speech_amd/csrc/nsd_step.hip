@@ -333,9 +333,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint32_t F = want ? C : 0u;
         const double *keys = L.cKey;
         bool compacted = false, full_scan = false;
-        // ---- threshold: at most 2G survivors ----
-        if (__ballot(want && C > 2u * G) != 0) {
-            bool searching = want && C > 2u * G;
+        // ---- threshold: at most fcap survivors (one per lane when the beam allows it) ----
+        const uint32_t fcap = (2u * (uint32_t)nsel <= (uint32_t)G) ? (uint32_t)G : 2u * (uint32_t)G;
+        if (__ballot(want && C > fcap) != 0) {
+            bool searching = want && C > fcap;
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
             bool ok = false;
             for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
@@ -365,7 +366,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 if (searching) {
                     if (!have) { full_scan = true; searching = false; }       // clustered / tied keys
                     else if (c < (uint32_t)nsel) hi = pivot;
-                    else if (c > 2u * G) lo = pivot;
+                    else if (c > fcap) lo = pivot;
                     else { ok = true; tau = pivot; F = c; searching = false; }
                 }
             }
@@ -395,8 +396,13 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             if (Fmax <= (uint32_t)G) {
                 // one candidate per lane; reads past a group's F compare against that group's own stale
                 // buffer entries and are discarded by the q < F test
+                if (UPW == 1) {
 #pragma unroll 4
-                for (uint32_t q = 0; q < Fmax; ++q) r0 += (q < F && keys[q] > k0) ? 1u : 0u;
+                    for (uint32_t q = 0; q < Fmax; ++q) r0 += (keys[q] > k0) ? 1u : 0u;
+                } else {
+#pragma unroll 4
+                    for (uint32_t q = 0; q < Fmax; ++q) r0 += (q < F && keys[q] > k0) ? 1u : 0u;
+                }
             } else {
 #pragma unroll 2
                 for (uint32_t q = 0; q < Fmax; ++q) {
@@ -544,13 +550,13 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 const uint32_t w = rank[k] + (VARIANT == NSD_VARIANT_U ? 1u : 0u);
                 emit(fb && rank[k] < (uint32_t)kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)r));
             }
+            nsd_wave_sync();                       // rowbuf is reused by the next pass
         }
-        nsd_wave_sync();
-        score_new(scored);
-        scored = C;
-        nsd_wave_sync();
     }
     NSD_STAMP(2);
+    nsd_wave_sync();
+    score_new(scored);
+    nsd_wave_sync();
     NSD_STAMP(3);
 
     // ---------------- final selection ----------------
