@@ -106,12 +106,28 @@ NSD_D float nsd_det_logf(float t)
 // exponentials left to right, then the 8 partial sums are combined pairwise
 // at lane distance 1, 2, 4 (every lane ends with the same total).
 // x[] is replaced by the log-probabilities.
+// value of the lane at distance 1, 2 (inside the quad) and of the mirrored lane of the 8-lane row, by DPP
+NSD_D float nsd_dpp_xor1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+NSD_D float nsd_dpp_xor2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+NSD_D float nsd_dpp_half_mirror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+}
+
 NSD_D void nsd_row_log_softmax5(float (&x)[5])
 {
+    // After the distance-1 and distance-2 steps the four lanes of a quad hold the same value, so the
+    // mirrored lane (7 - i) of the other quad carries exactly what the lane at distance 4 carries.
     float m = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), x[4]);
-    m = fmaxf(m, __shfl_xor(m, 1));
-    m = fmaxf(m, __shfl_xor(m, 2));
-    m = fmaxf(m, __shfl_xor(m, 4));
+    m = fmaxf(m, nsd_dpp_xor1(m));
+    m = fmaxf(m, nsd_dpp_xor2(m));
+    m = fmaxf(m, nsd_dpp_half_mirror(m));
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -119,9 +135,9 @@ NSD_D void nsd_row_log_softmax5(float (&x)[5])
         float e = nsd_det_expf(x[k]);
         s = (k == 0) ? e : s + e;
     }
-    s = s + __shfl_xor(s, 1);
-    s = s + __shfl_xor(s, 2);
-    s = s + __shfl_xor(s, 4);
+    s = s + nsd_dpp_xor1(s);
+    s = s + nsd_dpp_xor2(s);
+    s = s + nsd_dpp_half_mirror(s);
     float lse = nsd_det_logf(s);
 #pragma unroll
     for (int k = 0; k < 5; ++k) x[k] = x[k] - lse;
@@ -233,7 +249,8 @@ NSD_D NsdLmStep nsd_lm_advance(const NsdTables &t, int me, uint64_t ctxe, uint32
 // compiler + LDS ordering point between lanes of one wave
 NSD_D void nsd_wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // LDS only: lanes of a wave exchange data through LDS, never through global memory
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }

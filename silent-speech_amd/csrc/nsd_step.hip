@@ -474,6 +474,20 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const int npass = act ? (nlive + RPP - 1) / RPP : 0;
     const int npass_max = (int)wave_max((uint32_t)npass);
     uint32_t scored = 0;                          // candidates [0, scored) already have their key
+    // logits of the next pass are requested before the current pass is processed
+    float xn[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch_row = [&](int pass) {
+        const int slot = pass * RPP + (gl >> 3);
+        if (act && slot < nlive) {
+            const float *row = a.logits + ((size_t)u * B + (int)L.live[slot]) * NSD_V + j * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xn[k] = row[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xn[k] = 0.0f;
+        }
+    };
+    if (npass_max > 0) fetch_row(0);
     for (int pass = 0; pass < npass_max; ++pass) {
         const int slot = pass * RPP + (gl >> 3);
         const bool live = act && slot < nlive;
@@ -509,14 +523,9 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
 
         float x[5];
-        if (live) {
-            const float *row = a.logits + ((size_t)u * B + r) * NSD_V + j * 5;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = row[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = 0.0f;
-        }
+        for (int k = 0; k < 5; ++k) x[k] = xn[k];
+        if (pass + 1 < npass_max) fetch_row(pass + 1);
         nsd_row_log_softmax5(x);
 
 #pragma unroll
