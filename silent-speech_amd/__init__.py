@@ -4,7 +4,8 @@ The directory is named ``silent-speech_amd``; it is importable as
 ``silent_speech_amd`` through the symlink of that name at the repository root.
 """
 from .tables import (BASE_CHARS, BOS_ID, EOS_ID, PAD_ID, SPACE_ID, VOCAB, HostTrie, NgramTables,  # noqa: F401
-                     compile_ngram, flatten_trie, load_lexicon_words)
+                     compile_ngram, flatten_trie, load_lexicon_words, load_tables, save_tables)
+from .text import build_lexicon, postprocess  # noqa: F401
 
 
 class TextTransform:

@@ -387,3 +387,35 @@ def host_automaton_logp(t: NgramTables, text: str) -> float:
         else:
             cid = CTX_NONE
     return total
+
+
+# ----------------------------------------------------------------------
+# on-disk format of the replicated tables: one .npz (arrays only, nothing is unpickled on load)
+# ----------------------------------------------------------------------
+TABLE_FORMAT_VERSION = 1
+
+
+def save_tables(path: str, nodes: np.ndarray, ngram: Optional[NgramTables]) -> None:
+    """Write the flat trie and (optionally) the n-gram tables to ``path`` (.npz)."""
+    arrays = {"version": np.array([TABLE_FORMAT_VERSION], np.int64), "nodes": nodes.view(np.uint8).reshape(-1)}
+    if ngram is not None:
+        arrays.update(order=np.array([ngram.order], np.int64), vsz=np.array([ngram.vsz], np.int64),
+                      unseen=np.array([ngram.unseen], np.float64), init_ctx=np.array([ngram.init_ctx], np.int64),
+                      grams=ngram.grams.view(np.uint8).reshape(-1), ctxs=ngram.ctxs.view(np.uint8).reshape(-1),
+                      ctx_recs=ngram.ctx_recs.view(np.uint8).reshape(-1),
+                      gram_recs=ngram.gram_recs.view(np.uint8).reshape(-1))
+    np.savez(path, **arrays)
+
+
+def load_tables(path: str):
+    """Inverse of save_tables: (nodes, NgramTables or None)."""
+    with np.load(path, allow_pickle=False) as z:
+        if int(z["version"][0]) != TABLE_FORMAT_VERSION:
+            raise ValueError(f"unsupported table file version {int(z['version'][0])}")
+        nodes = z["nodes"].view(NODE_DTYPE).copy()
+        if "order" not in z.files:
+            return nodes, None
+        ngram = NgramTables(int(z["order"][0]), z["grams"].view(GRAM_DTYPE).copy(), z["ctxs"].view(CTX_DTYPE).copy(),
+                            float(z["unseen"][0]), int(z["vsz"][0]), z["ctx_recs"].view(CTXREC_DTYPE).copy(),
+                            z["gram_recs"].view(GRAMREC_DTYPE).copy(), int(z["init_ctx"][0]))
+    return nodes, ngram
