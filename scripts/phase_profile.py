@@ -30,7 +30,7 @@ tg, tl = S.pack_targets(S.make_sentences(words, N, 1000, 3, 7))
 tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
 dec = NSDecoder(DeviceTables.from_words(words, lm), 16, 64, variant=variant, lm_weight=0.05, word_bonus=0.35)
 ws = dec.workspace(N)
-stamps = torch.zeros(N, 8, dtype=torch.int64, device=dev)   # one row per wave (a wave carries 64/G utterances)
+stamps = torch.zeros(N, 16, dtype=torch.int64, device=dev)   # one row per wave (a wave carries 64/G utterances)
 L = lib.load()
 L.nsd_debug_set_stamps.argtypes = [C.c_void_p]
 assert L.nsd_debug_set_stamps(stamps.data_ptr()) == 0
@@ -47,7 +47,11 @@ for t in range(40):
         s = stamps.cpu().numpy()
         act = s[:, 5] > 0
         d = np.diff(s[act, :6], axis=1).astype(np.float64)
+        fine = {"pass0: lds+prefetch": s[act, 6] - s[act, 1], "pass0: softmax": s[act, 7] - s[act, 6],
+                "pass0: emit": s[act, 8] - s[act, 7], "final select: threshold": s[act, 9] - s[act, 3],
+                "final select: rank": s[act, 4] - s[act, 9]}
         tot = (s[act, 5] - s[act, 0]).astype(np.float64)
         span = (s[act, 5].max() - s[act, 0].min())
         print(f"step {t:2d}: active waves {act.sum():5d}  kernel {e0.elapsed_time(e1)*1e3:6.1f} us  "
-              f"wave mean {tot.mean():8.0f} ticks  span {span} ticks | " + "  ".join(f"{n} {d[:,i].mean():7.0f}" for i, n in enumerate(names)))
+              f"wave mean {tot.mean():8.0f} ticks  span {span} ticks | " + "  ".join(f"{n} {d[:,i].mean():7.0f}" for i, n in enumerate(names)) +
+              " || " + "  ".join(f"{k} {v.mean():6.0f}" for k, v in fine.items()))
