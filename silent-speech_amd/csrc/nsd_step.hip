@@ -192,21 +192,6 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const uint32_t CAP = a.cap;
     GroupLds L = carve<G>(smem + ((size_t)wid * UPW + g) * a.lds_per_utt, B, CAP, VARIANT == NSD_VARIANT_E);
 
-    // The logits of the first two passes are requested before anything else, assuming that unfinished
-    // hypotheses occupy the leading ranks (row == slot); rows where that turns out wrong are fetched again.
-    const int j = lane & 7;
-    float xs0[5], xs1[5];
-    {
-        const int s0 = gl >> 3, s1 = RPP + (gl >> 3);
-        const float *row0 = a.logits + ((size_t)u * B + s0) * NSD_V + j * 5;
-        const float *row1 = a.logits + ((size_t)u * B + s1) * NSD_V + j * 5;
-        const bool f0 = act && s0 < nbeams, f1 = act && s1 < nbeams;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) xs0[k] = f0 ? row0[k] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) xs1[k] = f1 ? row1[k] : 0.0f;
-    }
-
     // ---------------- phase 1: hypothesis state -> LDS ----------------
     bool my_live = false;
     if (gl == 0) L.total[0] = 0;
@@ -281,92 +266,61 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         C += (uint32_t)__popcll(gb);
     };
 
-    // score candidates [from, C) of this group, one lane each; two rounds are handled together so that
-    // both automaton record loads are in flight before either is waited for
+    // score candidates [from, C) of this group, one lane each
     auto score_new = [&](uint32_t from) {
         const uint32_t rounds = wave_max(act && C > from ? (C - from + G - 1) / G : 0u);
-        for (uint32_t rd = 0; rd < rounds; rd += 2) {
-            uint32_t idx[2], info[2];
-            bool val[2], hit[2];
-            ulonglong2 rec[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                idx[h] = from + (rd + h) * G + gl;
-                val[h] = act && idx[h] < C;
-                info[h] = val[h] ? L.cInfo[idx[h]] : pack_info(0, K_CARRY, 0, 0);
-                hit[h] = false;
-                rec[h] = {0ull, 0ull};
-                const uint32_t tok = info[h] & 0x3f, kind = (info[h] >> 6) & 3, p = info[h] >> 14;
-                if (val[h] && use_lm && kind == K_CHAR && tok != NSD_SPACE) {
-                    const int glen = (int)(L.bMeta[p] >> 8);
-                    const uint64_t symmask = L.bSym[p];
-                    const uint32_t sym = tok + 1u;
-                    if (glen + 2 >= order && L.bCtxeId[p] != NSD_CTX_NONE && ((symmask >> sym) & 1ull)) {
-                        const NsdGramRec *g = a.tab.gram_recs + L.bLmBase[p] + __popcll(symmask & ((1ull << sym) - 1ull));
-                        rec[h] = *reinterpret_cast<const ulonglong2 *>(g);      // logp, term_next
-                        hit[h] = true;
+        for (uint32_t rd = 0; rd < rounds; ++rd) {
+            const uint32_t i = from + rd * G + gl;
+            if (!(act && i < C)) continue;
+            const uint32_t info = L.cInfo[i];
+            const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = info >> 14;
+            const double lp = (double)reinterpret_cast<const float *>(L.cKey)[2 * i];
+            const double sb = L.bScore[p];
+            const uint32_t meta = L.bMeta[p];
+            const int glen = (int)(meta >> 8);
+            double score;
+            int Lnew = glen + 1;
+            if (kind == K_CARRY) {
+                score = sb;
+                Lnew = glen > 1 ? glen : 1;
+            } else if (kind == K_FALLBACK) {
+                score = sb + (lp - P.gamma);
+            } else if (kind == K_EOS && VARIANT == NSD_VARIANT_U) {
+                score = sb + lp;
+            } else {
+                const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
+                const int ms = 1 + glen - pend;
+                const bool whole = (L.bMask[p] >> 37) & 1;
+                double add = lp;
+                if (kind == K_EOS || tok == NSD_SPACE) {
+                    // both score the stripped surface: logp(surf + " ") == logp(surf)
+                    double lg = L.bG[p];
+                    if (ms + 1 >= order) lg = lg + L.bTermS[p];
+                    if (kind == K_EOS) {                   // variant E boundary EOS (eval_ar.py:290-296)
+                        add -= P.eos_len_nudge * (double)glen;
+                        if (use_lm && glen > 0) add += P.beta * lg;
+                    } else {
+                        if (use_lm) add += P.beta * lg;
+                        if (!whole) add -= P.gamma;
+                        if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
                     }
+                } else if (use_lm) {
+                    const uint64_t ctx = L.bCtx[p];
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p],
+                                                       L.bBo[p], tok + 1u);
+                    double lg = L.bGe[p];
+                    if (s.has_int) lg = lg + s.lint;
+                    if (s.full_new) lg = lg + s.term;
+                    add += P.beta * lg;
                 }
+                score = sb + add;
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (!val[h]) continue;
-                const uint32_t i = idx[h];
-                const uint32_t tok = info[h] & 0x3f, kind = (info[h] >> 6) & 3, p = info[h] >> 14;
-                const double lp = (double)reinterpret_cast<const float *>(L.cKey)[2 * i];
-                const double sb = L.bScore[p];
-                const uint32_t meta = L.bMeta[p];
-                const int glen = (int)(meta >> 8);
-                double score;
-                int Lnew = glen + 1;
-                if (kind == K_CARRY) {
-                    score = sb;
-                    Lnew = glen > 1 ? glen : 1;
-                } else if (kind == K_FALLBACK) {
-                    score = sb + (lp - P.gamma);
-                } else if (kind == K_EOS && VARIANT == NSD_VARIANT_U) {
-                    score = sb + lp;
-                } else {
-                    const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
-                    const int ms = 1 + glen - pend;
-                    const bool whole = (L.bMask[p] >> 37) & 1;
-                    double add = lp;
-                    if (kind == K_EOS || tok == NSD_SPACE) {
-                        // both score the stripped surface: logp(surf + " ") == logp(surf)
-                        double lg = L.bG[p];
-                        if (ms + 1 >= order) lg = lg + L.bTermS[p];
-                        if (kind == K_EOS) {                   // variant E boundary EOS (eval_ar.py:290-296)
-                            add -= P.eos_len_nudge * (double)glen;
-                            if (use_lm && glen > 0) add += P.beta * lg;
-                        } else {
-                            if (use_lm) add += P.beta * lg;
-                            if (!whole) add -= P.gamma;
-                            if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
-                        }
-                    } else if (use_lm) {
-                        double lg = L.bGe[p];
-                        if (hit[h]) {
-                            // seen n-gram in a seen context: both windows exist (the context is full)
-                            lg = lg + __longlong_as_double((long long)rec[h].x);
-                            lg = lg + __longlong_as_double((long long)rec[h].y);
-                        } else {
-                            const uint64_t ctx = L.bCtx[p];
-                            const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                            const NsdLmStep st = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p],
-                                                                L.bLmBase[p], L.bBo[p], tok + 1u);
-                            if (st.has_int) lg = lg + st.lint;
-                            if (st.full_new) lg = lg + st.term;
-                        }
-                        add += P.beta * lg;
-                    }
-                    score = sb + add;
-                }
-                if (VARIANT == NSD_VARIANT_E) {
-                    L.cScore[i] = score;
-                    L.cKey[i] = score / P.len_denom[Lnew];
-                } else {
-                    L.cKey[i] = score;
-                }
+            if (VARIANT == NSD_VARIANT_E) {
+                L.cScore[i] = score;
+                L.cKey[i] = score / P.len_denom[Lnew];
+            } else {
+                L.cKey[i] = score;
             }
         }
     };
@@ -517,74 +471,80 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const bool may_overflow = __ballot(act && L.total[0] > CAP) != 0;
 
     // ---------------- passes: log-softmax, candidates, scores ----------------
+    const int j = lane & 7;
     const int npass = act ? (nlive + RPP - 1) / RPP : 0;
     const int npass_max = (int)wave_max((uint32_t)npass);
     uint32_t scored = 0;                          // candidates [0, scored) already have their key
-
-    struct PassCtx { uint64_t mask; int r, kfb; bool live, eos_u, eos_e, fb; };
-    auto pass_ctx = [&](int pass) -> PassCtx {
-        PassCtx pc;
+    // logits of the next pass are requested before the current pass is processed
+    float xn[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch_row = [&](int pass) {
         const int slot = pass * RPP + (gl >> 3);
-        pc.live = act && slot < nlive;
-        pc.r = pc.live ? (int)L.live[slot] : 0;
-        const uint32_t meta = L.bMeta[pc.r];
-        pc.mask = pc.live ? L.bMask[pc.r] : 0;
-        const int glen = (int)(meta >> 8);
-        const bool whole = (pc.mask >> 37) & 1;
-        const bool pend = (meta & NSD_F_PENDING_SPACE) != 0;
-        pc.eos_u = pc.live && VARIANT == NSD_VARIANT_U && P.allow_eos_anytime;
-        pc.eos_e = pc.live && VARIANT == NSD_VARIANT_E && pc.mask != 0 &&
-                   glen >= P.min_len_for_eos && (pend || whole);
-        pc.fb = pc.live && pc.mask == 0 && !pc.eos_e;
-        pc.kfb = B;
-        if (pc.kfb > NSD_V) { pc.kfb = NSD_V; if (VARIANT != NSD_VARIANT_U && pc.fb) err_topk = true; }
-        return pc;
-    };
-    // logits row of the pass for this lane (zeros where the pass has no row for it)
-    auto fetch_row = [&](const PassCtx &pc, float (&x)[5]) {
-        if (pc.live) {
-            const float *row = a.logits + ((size_t)u * B + pc.r) * NSD_V + j * 5;
+        if (act && slot < nlive) {
+            const float *row = a.logits + ((size_t)u * B + (int)L.live[slot]) * NSD_V + j * 5;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = row[k];
+            for (int k = 0; k < 5; ++k) xn[k] = row[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = 0.0f;
+            for (int k = 0; k < 5; ++k) xn[k] = 0.0f;
         }
     };
-    // the early request assumed row == slot
-    auto fix_row = [&](const PassCtx &pc, int pass, float (&x)[5]) {
-        if (!pc.live || pc.r != pass * RPP + (gl >> 3)) fetch_row(pc, x);
-    };
-    // the buffer must hold what the pass can add; otherwise prune it to its top-B first
-    auto make_room = [&](const PassCtx &pc) {
-        uint32_t add = 0;
-        if (pc.live && j == 0)
-            add = pc.fb ? (uint32_t)pc.kfb + (pc.eos_u ? 1u : 0u)
-                        : (uint32_t)__popcll(pc.mask & ((1ull << NSD_NBASE) - 1)) + ((pc.eos_u || pc.eos_e) ? 1u : 0u);
+    if (npass_max > 0) fetch_row(0);
+    for (int pass = 0; pass < npass_max; ++pass) {
+        const int slot = pass * RPP + (gl >> 3);
+        const bool live = act && slot < nlive;
+        const int r = live ? (int)L.live[slot] : 0;
+        const uint32_t meta = L.bMeta[r];
+        const uint64_t mask = live ? L.bMask[r] : 0;
+        const int glen = (int)(meta >> 8);
+        const bool whole = (mask >> 37) & 1;
+        const bool pend = (meta & NSD_F_PENDING_SPACE) != 0;
+        const bool eos_u = live && VARIANT == NSD_VARIANT_U && P.allow_eos_anytime;
+        const bool eos_e = live && VARIANT == NSD_VARIANT_E && mask != 0 &&
+                           glen >= P.min_len_for_eos && (pend || whole);
+        const bool fb = live && mask == 0 && !eos_e;
+        int kfb = B;
+        if (kfb > NSD_V) { kfb = NSD_V; if (VARIANT != NSD_VARIANT_U && fb) err_topk = true; }
+
+        // the buffer must hold what this pass can add; otherwise prune it to its top-B first
+        if (may_overflow) {
+            uint32_t add = 0;
+            if (live && j == 0)
+                add = fb ? (uint32_t)kfb + (eos_u ? 1u : 0u)
+                         : (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + ((eos_u || eos_e) ? 1u : 0u);
 #pragma unroll
-        for (int off = 8; off < G; off <<= 1) add += __shfl_xor(add, off);
-        add = __shfl(add, gshift);
-        const bool over = act && C + add > CAP;
-        if (__ballot(over) != 0) {
-            if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored); nsd_wave_sync(); }
-            scored = C;
-            prune(over);
-            if (over) scored = C;
+            for (int off = 8; off < G; off <<= 1) add += __shfl_xor(add, off);
+            add = __shfl(add, gshift);
+            const bool over = act && C + add > CAP;
+            if (__ballot(over) != 0) {
+                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored); nsd_wave_sync(); }
+                scored = C;
+                prune(over);
+                if (over) scored = C;
+            }
         }
-    };
-    auto emit_pass = [&](const PassCtx &pc, float (&x)[5]) {
+
+        float x[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) x[k] = xn[k];
+        if (pass + 1 < npass_max) fetch_row(pass + 1);
+        if (pass == 0) NSD_STAMP(6);
+        nsd_row_log_softmax5(x);
+        if (pass == 0) NSD_STAMP(7);
+
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const uint32_t v = (uint32_t)(j * 5 + k);
-            const bool is_char = pc.live && v < NSD_NBASE && ((pc.mask >> v) & 1);
-            const bool is_eos = (v == NSD_EOS) && (pc.eos_u || pc.eos_e);
+            const bool is_char = live && v < NSD_NBASE && ((mask >> v) & 1);
+            const bool is_eos = (v == NSD_EOS) && (eos_u || eos_e);
             uint32_t w = v, kind = K_CHAR;
             if (VARIANT == NSD_VARIANT_U) w = v + 1;
             if (is_eos) { kind = K_EOS; w = (VARIANT == NSD_VARIANT_U) ? 0u : 40u; }
-            emit(is_char || is_eos, x[k], pack_info(v, kind, w, (uint32_t)pc.r));
+            emit(is_char || is_eos, x[k], pack_info(v, kind, w, (uint32_t)r));
         }
+
+        if (pass == 0) NSD_STAMP(8);
         // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
-        if (__ballot(pc.fb) != 0) {
+        if (__ballot(fb) != 0) {
             float *rb = L.rowbuf + (gl >> 3) * NSD_V;
 #pragma unroll
             for (int k = 0; k < 5; ++k) rb[j * 5 + k] = x[k];
@@ -601,50 +561,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             for (int k = 0; k < 5; ++k) {
                 const uint32_t v = (uint32_t)(j * 5 + k);
                 const uint32_t w = rank[k] + (VARIANT == NSD_VARIANT_U ? 1u : 0u);
-                emit(pc.fb && rank[k] < (uint32_t)pc.kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)pc.r));
+                emit(fb && rank[k] < (uint32_t)kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)r));
             }
             nsd_wave_sync();                       // rowbuf is reused by the next pass
         }
-    };
-
-    // Two passes per iteration: their log-softmax chains are independent, so issuing them side by side
-    // hides the latency of each dependent step behind the other; candidates are still emitted in pass order.
-    float xna[5], xnb[5];                         // rows of the next two passes, requested one iteration ahead
-    if (npass_max > 0) {
-        const PassCtx pa = pass_ctx(0), pb = pass_ctx(1);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { xna[k] = xs0[k]; xnb[k] = xs1[k]; }
-        fix_row(pa, 0, xna);
-        fix_row(pb, 1, xnb);
-    }
-    for (int pass = 0; pass < npass_max; pass += 2) {
-        const bool two = pass + 1 < npass_max;
-        const PassCtx pa = pass_ctx(pass), pb = pass_ctx(pass + 1);
-        float xa[5], xb[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { xa[k] = xna[k]; xb[k] = xnb[k]; }
-        if (pass + 2 < npass_max) {
-            fetch_row(pass_ctx(pass + 2), xna);
-            fetch_row(pass_ctx(pass + 3), xnb);
-        }
-        if (pass == 0) NSD_STAMP(6);
-        if (!may_overflow) {
-            nsd_row_log_softmax5(xa);
-            nsd_row_log_softmax5(xb);
-            if (pass == 0) NSD_STAMP(7);
-            emit_pass(pa, xa);
-            if (two) emit_pass(pb, xb);
-        } else {
-            make_room(pa);
-            nsd_row_log_softmax5(xa);
-            emit_pass(pa, xa);
-            if (two) {
-                make_room(pb);
-                nsd_row_log_softmax5(xb);
-                emit_pass(pb, xb);
-            }
-        }
-        if (pass == 0) NSD_STAMP(8);
     }
     NSD_STAMP(2);
     nsd_wave_sync();

@@ -6,12 +6,14 @@ with an error that says how to build it.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-SO_PATH = PKG / "libnsdecode.so"
+# NSDECODE_LIB selects another build of the same library (diagnostic and experimental builds)
+SO_PATH = Path(os.environ.get("NSDECODE_LIB") or PKG / "libnsdecode.so")
 
 MAX_BEAM = 64
 MAX_STEPS = 128
