@@ -118,6 +118,48 @@ def cpu_baseline(words, corpus, targets, args, gpu_texts):
             "transcript_mismatches_vs_gpu": mism}
 
 
+def _cpu_shard(job):
+    """Worker of the all-cores CPU figure: decodes its own utterances until the time is up."""
+    (words, corpus, targets, u_first, seed, utt0, margin, beam, tmax, order, variant, beta, gamma, kappa, seconds) = job
+    from oracle import ns_oracle as O, synth
+    torch.set_num_threads(1)
+    trie = O.build_trie(words)
+    lm = O.NgramLM(order, floor_vsz=(variant == "U")).fit(corpus)
+    chars = done = 0
+    t0 = time.perf_counter()
+    for k, target in enumerate(targets):
+        useed = synth.utt_seed(seed, utt0 + u_first + k)
+        tgt = synth.text_to_tokens(target)
+        step_fn = lambda ids: torch.from_numpy(synth.logits_row(useed, ids, tgt, margin)).unsqueeze(0)
+        ids = O.constrained_beam_decode(step_fn, O.TextTransformLike, beam, tmax, trie, lm, lm_weight=beta,
+                                        oov_penalty=gamma, variant=variant, word_bonus=kappa)
+        chars += len(O.ids_to_text(O.TextTransformLike, ids))
+        done += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    return chars, done, time.perf_counter() - t0
+
+
+def cpu_all_cores(words, corpus, targets, args):
+    """The same Python restatement with the utterances sharded over worker processes, one per core of this
+    job's CPU share: the figure a user of the reference gets by running one copy per core."""
+    import multiprocessing as mp
+    cores = max(1, min(args.cpu_procs, os.cpu_count() or 1))
+    per = max(1, min(len(targets) // cores, args.cpu_utts))
+    jobs = [(words, corpus, targets[w * per:(w + 1) * per], w * per, args.seed, args.utt0, args.margin, args.beam,
+             args.tmax, args.order, args.variant, args.beta, args.gamma, args.kappa, args.cpu_seconds_all)
+            for w in range(cores)]
+    from concurrent.futures import ProcessPoolExecutor
+    # a worker that dies breaks the pool with an exception instead of hanging the bench
+    with ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:
+        out = list(pool.map(_cpu_shard, jobs, timeout=args.cpu_seconds_all * 4 + 120))
+    chars = sum(o[0] for o in out)
+    wall = max(o[2] for o in out)
+    return {"value": chars / wall, "unit": "chars/s", "cores": cores,
+            "sample": f"{sum(o[1] for o in out)} utterances over {cores} processes ({chars} chars, {wall:.1f} s "
+                      f"after start-up)"}
+
+
 def secondary_variant(args, variant, words, corpus, tgd, tld, targets):
     """Same batch through another copy of the decoder: chars/s and the nsd_step roofline, briefly."""
     import copy
@@ -189,6 +231,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=4, help="time the nsd_step launches of every n-th decode")
     ap.add_argument("--cpu-utts", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--cpu-seconds-all", type=float, default=8.0,
+                    help="time limit of the all-cores CPU figure (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=16, help="worker processes of the all-cores CPU figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse "
                                                              "several ranks on one GPU")
@@ -342,6 +387,8 @@ def main():
     if not args.no_cpu and world == 1:
         result["cpu_baseline"] = cpu_baseline(words, corpus, targets, args, texts)
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        if args.cpu_seconds_all > 0:
+            result["cpu_baseline"]["all_cores"] = cpu_all_cores(words, corpus, targets, args)
         result["speedup_vs_cpu_1core"] = result["value"] / result["cpu_baseline"]["value"]
     print(json.dumps(result), flush=True)
     if world > 1:

@@ -255,6 +255,39 @@ int nsd_rerank_lm(const NsdTables *t, const uint8_t *ar_ids, const int32_t *ar_l
 int nsd_rerank_gather(const float *logits, const uint8_t *target, const int32_t *len,
                       int32_t N, int32_t L, int32_t V, double *out, void *stream);
 
+/* Which copy of CharNgramLM.cond_dist forms the context (they differ only at order 1):
+ *   U  scripts/ns_utils.py:111-136  last order-1 characters, left-padded with '^'
+ *   T  train_emg_llm.py:88-107      one '^' in front when fewer than order-1 characters are there;
+ *                                   order 1 keeps the whole context, so only the empty one matches */
+#define NSD_PRIOR_U 0
+#define NSD_PRIOR_T 1
+
+/* Next-character prior of the n-gram tables: add-one smoothed P(ch | context) over the 37 base
+ * characters as fp32, renormalised (CharNgramLM.cond_dist, see above).
+ *   ctx_ids device [N, stride] u8 base-character ids of the context (0..36; any other value is a
+ *           character outside the alphabet, which no count matches), ctx_len device [N] i32
+ *   probs   device [N, 37] fp32 */
+int nsd_cond_dist(const NsdTables *t, const uint8_t *ctx_ids, const int32_t *ctx_len, int32_t N, int32_t stride,
+                  int32_t form, float *probs, void *stream);
+
+/* The LM regulariser of training (train_emg_llm.py:254-316): mean over the positions whose target is
+ * not -100 of CE(prior || softmax(logits)), the prior being nsd_cond_dist of the row's earlier
+ * base-character targets, spread over the model vocabulary with 1e-8 added per entry and renormalised.
+ *   logits  device [B, L, V] fp32;  out_ids device [B, L] i64 targets, -100 = padding
+ *   pos_loss device [B*L] fp32: per-position cross entropy (0 at skipped positions)
+ *   stats    device [3] f64: sum of pos_loss, number of valid positions, mean (0 when there are none);
+ *            reduced in a fixed order, so repeated calls give the same bits */
+int nsd_lm_prior_ce(const NsdTables *t, const float *logits, const int64_t *out_ids, int32_t B, int32_t L, int32_t V,
+                    int32_t form, float *pos_loss, double *stats, void *stream);
+
+/* Gradient of that mean with respect to the logits (what autograd derives from
+ * train_emg_llm.py:276,300-303): grad_out * (softmax * sum(prior) - prior) / count at valid positions,
+ * 0 elsewhere.  stats is the array nsd_lm_prior_ce filled for the same inputs; grad_out device [1] fp32.
+ *   grad_logits device [B, L, V] fp32 */
+int nsd_lm_prior_ce_grad(const NsdTables *t, const float *logits, const int64_t *out_ids, int32_t B, int32_t L,
+                         int32_t V, int32_t form, const double *stats, const float *grad_out, float *grad_logits,
+                         void *stream);
+
 /* Row-wise deterministic fp32 log-softmax, the one nsd_step applies
  * (F.log_softmax at scripts/ns_utils.py:227).  x, out device [rows, V]. */
 int nsd_log_softmax(const float *x, int32_t rows, int32_t V, float *out, void *stream);

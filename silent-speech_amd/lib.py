@@ -21,6 +21,7 @@ TOKEN_CARRY = 0xFF
 U_DONE, U_ERR_TOPK, U_STEPS_SHIFT = 0x100, 0x200, 16
 F_FINISHED, F_DEAD, F_PENDING_SPACE = 1, 2, 4
 VARIANTS = {"U": 0, "I": 1, "E": 2}
+PRIOR_FORMS = {"U": 0, "T": 1}
 
 
 class NsdError(RuntimeError):
@@ -54,7 +55,7 @@ class BeamStatePtrs(C.Structure):
 EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "nsd_tables_destroy",
            "nsd_tables_order", "nsd_state_init", "nsd_step", "nsd_backtrace", "nsd_gather_ids",
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
-           "nsd_decode_synth", "nsd_rerank_lm"]
+           "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad"]
 
 _lib = None
 
@@ -90,6 +91,9 @@ def load():
     L.nsd_decode_synth.argtypes = [vp, C.POINTER(Params), C.POINTER(BeamStatePtrs), u64, i64, vp, vp, i32, C.c_float,
                                    vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.nsd_rerank_lm.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.nsd_cond_dist.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    L.nsd_lm_prior_ce.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.nsd_lm_prior_ce_grad.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

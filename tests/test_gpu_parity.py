@@ -430,3 +430,86 @@ def test_ctc_proposal_and_lm_rerank_pipeline(dev):
         assert float(scores[u, 1]).hex() == (float(lm.logp(hyp_ctc)) - 0.002 * len(hyp_ctc)).hex()
         n_ctc += int(choice[u])
     assert 0 < n_ctc < len(targets)
+
+
+# ---------------------------------------------------------------------------
+# next-character prior and the training regulariser
+# ---------------------------------------------------------------------------
+def _prior_golden():
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).parent / "golden" / "ns_prior_golden.json").read_text(encoding="utf-8"))
+
+
+def _f32(b64, shape):
+    import base64
+    return np.frombuffer(base64.b64decode(b64), np.float32).reshape(shape)
+
+
+@pytest.mark.gpu
+def test_cond_dist_matches_reference_values():
+    """nsd_cond_dist against CharNgramLM.cond_dist values recorded from both reference copies.
+    float32; the 37-term sum is taken in another order than torch's, hence 1e-6 relative."""
+    from silent_speech_amd.prior import cond_dist_batch, tables_from_lm
+    from silent_speech_amd.tables import NgramCounts
+    n = 0
+    for rec in _prior_golden()["cond_dist"]:
+        words = synth.make_lexicon(rec["n_words"], rec["lex_seed"], max_len=6)
+        corpus = synth.make_sentences(words, 300, rec["corpus_seed"])[:rec["n_corpus"]]
+        tab = tables_from_lm(NgramCounts(rec["order"]).fit(corpus))
+        got = cond_dist_batch(tab, rec["contexts"], form=rec["form"]).cpu().numpy()
+        want = _f32(rec["probs_f32"], (len(rec["contexts"]), 37))
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, err_msg=f"{rec['form']} order {rec['order']}")
+        n += len(want)
+    assert n > 150
+    # a character outside the alphabet matches nothing, as in the reference's dict lookups
+    lm = O.NgramLM(3).fit(corpus)
+    tab = tables_from_lm(NgramCounts(3).fit(corpus))
+    got = cond_dist_batch(tab, ["a!", "!a", ""], form="U").cpu().numpy()
+    for row, c in zip(got, ["a!", "!a", ""]):
+        np.testing.assert_allclose(row, O.cond_dist(lm, c, synth.BASE_CHARS, "U"), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_lm_regularizer_matches_reference_values():
+    """Loss and gradient of the regulariser against values recorded from train_emg_llm.py's own function
+    (torch autograd), and against the CPU restatement on a larger batch.  float32 end to end: loss within
+    2e-6 relative, gradient within 2e-5 relative."""
+    from silent_speech_amd.prior import ns_lm_regularizer, tables_from_lm
+    from silent_speech_amd.tables import NgramCounts
+    dev = torch.device("cuda", 0)
+    for rec in _prior_golden()["regularizer"]:
+        words = synth.make_lexicon(rec["n_words"], rec["lex_seed"], max_len=6)
+        corpus = synth.make_sentences(words, 300, rec["corpus_seed"])[:rec["n_corpus"]]
+        tab = tables_from_lm(NgramCounts(rec["order"]).fit(corpus))
+        rs = np.random.RandomState(rec["seed"])
+        logits = (rs.standard_normal((rec["B"], rec["L"], 40)) * rec["scale"]).astype(np.float32)
+        x = torch.from_numpy(logits).to(dev).requires_grad_(True)
+        out_ids = torch.tensor(rec["out_ids"], dtype=torch.int64, device=dev)
+        loss = ns_lm_regularizer(x, None, out_ids, tab)
+        want = float(_f32(rec["loss_f32"], (1,))[0])
+        assert abs(float(loss.detach()) - want) <= 2e-6 * max(1.0, abs(want)), rec["name"]
+        (loss * 1.0).backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), _f32(rec["grad_f32"], logits.shape), rtol=2e-5, atol=2e-8,
+                                   err_msg=rec["name"])
+    # a training-sized batch against the restatement, with an upstream factor as in the total loss
+    words = synth.make_lexicon(200, 0)
+    corpus = synth.make_sentences(words, 2000, 1)
+    lm = O.NgramLM(3).fit(corpus)
+    tab = tables_from_lm(NgramCounts(3).fit(corpus))
+    B, L = 16, 72
+    rs = np.random.RandomState(7)
+    logits = (rs.standard_normal((B, L, 40)) * 3).astype(np.float32)
+    out_ids = np.full((B, L), -100, np.int64)
+    for i, s in enumerate(synth.make_sentences(words, B, 55, 3, 7)):
+        toks = synth.text_to_tokens(s)[:L - 1] + [synth.EOS_ID]
+        out_ids[i, :len(toks)] = toks
+    x = torch.from_numpy(logits).to(dev).requires_grad_(True)
+    loss = ns_lm_regularizer(x, None, torch.from_numpy(out_ids).to(dev), tab)
+    (0.05 * loss).backward()
+    wl, wg = O.lm_regularizer(lm, logits, out_ids)
+    assert abs(float(loss.detach()) - float(wl)) <= 2e-6 * abs(float(wl))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 0.05 * wg, rtol=2e-5, atol=2e-8)
+    # same bits on a second call (fixed-order reduction)
+    loss2 = ns_lm_regularizer(x.detach(), None, torch.from_numpy(out_ids).to(dev), tab)
+    assert float(loss2) == float(loss.detach())
