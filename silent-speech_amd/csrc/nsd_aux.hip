@@ -482,34 +482,38 @@ extern "C" int nsd_rerank_gather(const float *logits, const uint8_t *target, con
 }
 
 // ---------------------------------------------------------------------
-// synthetic logits: 8 lanes per row, 5 values per lane
+// synthetic logits: one thread per 16-byte quarter-decade of a row (10 threads per row), so that a wave
+// writes 1 KB of consecutive bytes with one dwordx4 store per lane
 // ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 nsd_synth_logits_kernel(NsdBeamState st, uint64_t base_seed, long long utt0, const int8_t *targets,
-                        const int32_t *target_len, int stride, float margin, float *logits, int N, int B)
+                        const int32_t *target_len, int stride, float margin, float *logits, uint32_t nrows, uint32_t B)
 {
-    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const int j = threadIdx.x & 7;
-    if (row >= (long long)N * B) return;
-    const int u = (int)(row / B), r = (int)(row % B);
+    const uint32_t q4 = blockIdx.x * blockDim.x + threadIdx.x;          // index of the float4
+    const uint32_t row = q4 / 10u, c = q4 - row * 10u;
+    if (row >= nrows) return;
+    const uint32_t u = row / B, r = row - u * B;
+    // independent loads first (slots past the beam count hold stale values that are dropped below)
     const uint32_t um = st.utt[u];
-    if ((um & NSD_U_DONE) || r >= (int)(um & NSD_U_NBEAMS_MASK)) return;
     const uint32_t meta = st.meta[row];
+    const uint64_t hist = st.hist[row];
+    const int tlen = target_len[u];
+    if ((um & NSD_U_DONE) || r >= (um & NSD_U_NBEAMS_MASK)) return;
     if (meta & NSD_F_FINISHED) return;
     const int step = (int)(meta >> 8);
-    const int tgt = step < target_len[u] ? (int)targets[(size_t)u * stride + step] : NSD_EOS;
+    const int tgt = step < tlen ? (int)targets[(size_t)u * stride + step] : NSD_EOS;
     const uint64_t useed = nsd_mix64(base_seed + (uint64_t)(utt0 + u) * 0xD1B54A32D192ED03ull);
-    const uint64_t k = nsd_mix64(st.hist[row] ^ nsd_mix64(useed + (uint64_t)step * NSD_GOLD));
+    const uint64_t k = nsd_mix64(hist ^ nsd_mix64(useed + (uint64_t)step * NSD_GOLD));
     const uint32_t rk = (uint32_t)(k ^ (k >> 32));
-    float *dst = logits + row * NSD_V + j * 5;
+    float x[4];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int v = j * 5 + q;
-        const uint32_t h = nsd_fmix32(rk + (uint32_t)v * 0x9E3779B9u);
-        float x = ((float)(h >> 8) * 5.9604644775390625e-08f - 0.5f) * 4.0f;
-        if (v == tgt) x = x + margin;
-        dst[q] = x;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t v = c * 4u + q;
+        const uint32_t h = nsd_fmix32(rk + v * 0x9E3779B9u);
+        x[q] = ((float)(h >> 8) * 5.9604644775390625e-08f - 0.5f) * 4.0f;
+        if ((int)v == tgt) x[q] = x[q] + margin;
     }
+    reinterpret_cast<float4 *>(logits)[q4] = make_float4(x[0], x[1], x[2], x[3]);
 }
 
 extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int64_t utt0,
@@ -520,10 +524,11 @@ extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int6
     if (N < 0 || stride < 0) return NSD_E_SIZE;
     if (N == 0) return NSD_OK;
     if (!st || !targets || !target_len || !logits) return NSD_E_NULL;
-    const long long threads = (long long)N * B * 8;
+    const long long threads = (long long)N * B * 10;                    // float4s of the logits array
+    if (threads > 0xFFFFFFFFll) return NSD_E_SIZE;
     hipLaunchKernelGGL(nsd_synth_logits_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, *st, base_seed, (long long)utt0, targets, target_len, stride,
-                       margin, logits, N, B);
+                       margin, logits, (uint32_t)((long long)N * B), (uint32_t)B);
     return (int)hipGetLastError();
 }
 
