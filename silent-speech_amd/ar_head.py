@@ -1,0 +1,221 @@
+"""Batched, KV-cached AR head: what `EMGTextModel.step` (inference_emg_llm.py:83-88) computes, for all
+N utterances x B hypotheses of a decode step at once.
+
+The reference re-runs the frozen decoder-only LLM over the whole sequence [context ; char_embed(ids)] for one
+hypothesis at a time and keeps the last position (inference_emg_llm.py:427-429).  Here the context (soft prompt,
+prompt embeddings, EMG adapter output) is run once per utterance and its keys/values are shared by the
+utterance's hypotheses; every step then feeds ONE new token per hypothesis, after re-ordering the cache of the
+generated positions by the scorer's back-pointers.  The dense contractions stay torch / hipBLASLt; this module
+is plumbing around them (no hand-written kernels), and its output feeds `NSDecoder.step`.
+
+Architecture = transformers' LlamaModel (pre-norm, RMSNorm, rotary embedding in the rotate-half form, grouped
+query attention, SwiGLU MLP, final norm) + `char_embed` + `lm_head`; `from_hf` takes the weights of such a
+model so that the two can be compared position by position.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class LlamaDims:
+    hidden: int
+    layers: int
+    heads: int
+    kv_heads: int
+    head_dim: int
+    intermediate: int
+    rope_theta: float = 500000.0
+    rms_eps: float = 1e-5
+    vocab: int = 40
+
+
+# meta-llama/Llama-3.2-3B, the backbone the reference loads by default (inference_emg_llm.py:327)
+LLAMA_3_2_3B = LlamaDims(hidden=3072, layers=28, heads=24, kv_heads=8, head_dim=128, intermediate=8192)
+
+
+def _rms(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(x.dtype)
+
+
+def _rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """x [..., hd]; cos/sin broadcastable [..., hd] (both halves hold the same angles)."""
+    h = x.shape[-1] // 2
+    rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+    return x * cos + rot * sin
+
+
+class TorchLlamaStep:
+    """KV-cached batched equivalent of EMGTextModel.step for N utterances x B hypotheses."""
+
+    def __init__(self, dims: LlamaDims, *, dtype=torch.bfloat16, device=None, seed: int = 0,
+                 weights: Optional[dict] = None):
+        self.d = dims
+        self.dtype = dtype
+        self.device = torch.device(device if device is not None else "cuda")
+        if weights is None:
+            weights = self._random_weights(seed)
+        self.w = {k: v.to(self.device, dtype).contiguous() for k, v in weights.items()}
+        inv = 1.0 / (dims.rope_theta ** (torch.arange(0, dims.head_dim, 2, dtype=torch.float32) / dims.head_dim))
+        self.inv_freq = inv.to(self.device)
+        self.scale = 1.0 / math.sqrt(dims.head_dim)
+        self.N = self.B = self.S = self.T = 0
+
+    # ------------------------------------------------------------------ weights
+    def _random_weights(self, seed: int) -> dict:
+        d = self.d
+        # drawn on the target device: a 3B-parameter stand-in takes seconds there, minutes on the host
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        r = lambda *s: (torch.randn(*s, generator=g, device=self.device) * 0.02).to(self.dtype)
+        w = {"char_embed": r(d.vocab, d.hidden), "lm_head.w": r(d.vocab, d.hidden), "lm_head.b": torch.zeros(d.vocab),
+             "norm": torch.ones(d.hidden)}
+        for l in range(d.layers):
+            w[f"{l}.ln1"] = torch.ones(d.hidden)
+            w[f"{l}.ln2"] = torch.ones(d.hidden)
+            w[f"{l}.qkv"] = r((d.heads + 2 * d.kv_heads) * d.head_dim, d.hidden)
+            w[f"{l}.o"] = r(d.hidden, d.heads * d.head_dim)
+            w[f"{l}.gate_up"] = r(2 * d.intermediate, d.hidden)
+            w[f"{l}.down"] = r(d.hidden, d.intermediate)
+        return w
+
+    @classmethod
+    def from_hf(cls, llama, char_embed: torch.Tensor, lm_head_w: torch.Tensor, lm_head_b: torch.Tensor, *,
+                dtype=torch.float32, device=None) -> "TorchLlamaStep":
+        """From a transformers LlamaModel (no rope scaling) and the reference wrapper's char_embed / lm_head."""
+        c = llama.config
+        hd = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+        theta = getattr(c, "rope_theta", None)
+        if theta is None:
+            theta = (getattr(c, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
+        dims = LlamaDims(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, hd,
+                         c.intermediate_size, float(theta), float(c.rms_norm_eps), char_embed.shape[0])
+        sd = llama.state_dict()
+        w = {"char_embed": char_embed, "lm_head.w": lm_head_w, "lm_head.b": lm_head_b, "norm": sd["norm.weight"]}
+        for l in range(dims.layers):
+            p = f"layers.{l}."
+            w[f"{l}.ln1"] = sd[p + "input_layernorm.weight"]
+            w[f"{l}.ln2"] = sd[p + "post_attention_layernorm.weight"]
+            w[f"{l}.qkv"] = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"],
+                                       sd[p + "self_attn.v_proj.weight"]], 0)
+            w[f"{l}.o"] = sd[p + "self_attn.o_proj.weight"]
+            w[f"{l}.gate_up"] = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
+            w[f"{l}.down"] = sd[p + "mlp.down_proj.weight"]
+        return cls(dims, dtype=dtype, device=device, weights={k: v.detach().clone() for k, v in w.items()})
+
+    # ------------------------------------------------------------------ helpers
+    def _cos_sin(self, pos: torch.Tensor):
+        ang = pos.float()[..., None] * self.inv_freq                    # [..., hd/2]
+        ang = torch.cat((ang, ang), dim=-1)
+        return ang.cos().to(self.dtype), ang.sin().to(self.dtype)
+
+    def _split_qkv(self, qkv: torch.Tensor):
+        d = self.d
+        q, k, v = qkv.split([d.heads * d.head_dim, d.kv_heads * d.head_dim, d.kv_heads * d.head_dim], dim=-1)
+        return (q.unflatten(-1, (d.heads, d.head_dim)), k.unflatten(-1, (d.kv_heads, d.head_dim)),
+                v.unflatten(-1, (d.kv_heads, d.head_dim)))
+
+    def _mlp(self, l: int, x: torch.Tensor) -> torch.Tensor:
+        gu = F.linear(x, self.w[f"{l}.gate_up"])
+        g, u = gu.split(self.d.intermediate, dim=-1)
+        return F.linear(F.silu(g) * u, self.w[f"{l}.down"])
+
+    # ------------------------------------------------------------------ context (prefill)
+    @torch.no_grad()
+    def encode_context(self, context: torch.Tensor, beam: int, max_new_tokens: int) -> None:
+        """context [N, S, hidden] (soft prompt + prompt embeddings + EMG adapter output, what
+        EMGTextModel.encode_context returns): one causal pass; keys/values are kept per utterance."""
+        d = self.d
+        x = context.to(self.device, self.dtype)
+        N, S, _ = x.shape
+        self.N, self.B, self.S, self.T = N, int(beam), S, int(max_new_tokens)
+        M = N * self.B
+        cos, sin = self._cos_sin(torch.arange(S, device=self.device))    # [S, hd]
+        self.kp, self.vp = [], []
+        for l in range(d.layers):
+            h = _rms(x, self.w[f"{l}.ln1"], d.rms_eps)
+            q, k, v = self._split_qkv(F.linear(h, self.w[f"{l}.qkv"]))   # [N, S, heads, hd]
+            q = _rope(q, cos[None, :, None, :], sin[None, :, None, :]).transpose(1, 2)
+            k = _rope(k, cos[None, :, None, :], sin[None, :, None, :]).transpose(1, 2)   # [N, kvh, S, hd]
+            v = v.transpose(1, 2)
+            a = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True)
+            x = x + F.linear(a.transpose(1, 2).flatten(-2), self.w[f"{l}.o"])
+            x = x + self._mlp(l, _rms(x, self.w[f"{l}.ln2"], d.rms_eps))
+            self.kp.append(k.contiguous())
+            self.vp.append(v.contiguous())
+        # generated positions: [M, kvh, T, hd] per layer, two copies for the re-ordering
+        shape = (d.layers, M, d.kv_heads, max(self.T, 1), d.head_dim)
+        self.kg = [torch.zeros(shape, dtype=self.dtype, device=self.device) for _ in range(2)]
+        self.vg = [torch.zeros(shape, dtype=self.dtype, device=self.device) for _ in range(2)]
+        self.cur = 0
+        self.t = 0
+
+    # ------------------------------------------------------------------ one decode step
+    @torch.no_grad()
+    def step(self, tokens: torch.Tensor, parent: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tokens [N*B] int64: the last token of every hypothesis (BOS at the first step); parent [N*B] int64:
+        global index of the hypothesis each one extends (the scorer's back-pointer + u*B), None at the first
+        step.  Returns float32 logits [N*B, vocab]."""
+        d, t, S, N, B = self.d, self.t, self.S, self.N, self.B
+        M = N * B
+        if t >= self.T:
+            raise ValueError("all max_new_tokens steps already ran")
+        reorder = parent is not None and t > 0
+        kg_old, vg_old = self.kg[self.cur], self.vg[self.cur]
+        if reorder:
+            self.cur = 1 - self.cur
+        kg, vg = self.kg[self.cur], self.vg[self.cur]
+        x = F.embedding(tokens, self.w["char_embed"])                     # [M, hidden]
+        cos, sin = self._cos_sin(torch.full((1,), S + t, device=self.device))
+        g = d.heads // d.kv_heads
+        for l in range(d.layers):
+            h = _rms(x, self.w[f"{l}.ln1"], d.rms_eps)
+            q, k, v = self._split_qkv(F.linear(h, self.w[f"{l}.qkv"]))   # [M, heads, hd]
+            q = _rope(q, cos, sin)
+            if reorder:
+                # generated keys/values follow their hypotheses (layer by layer, into the other copy)
+                kg[l, :, :, :t] = kg_old[l].index_select(0, parent)[:, :, :t]
+                vg[l, :, :, :t] = vg_old[l].index_select(0, parent)[:, :, :t]
+            kg[l, :, :, t] = _rope(k, cos, sin)
+            vg[l, :, :, t] = v
+            # context part: the B hypotheses of an utterance share keys/values -> extra query rows
+            qn = q.view(N, B, d.kv_heads, g, d.head_dim).permute(0, 2, 1, 3, 4).reshape(N, d.kv_heads, B * g, d.head_dim)
+            sp = torch.matmul(qn, self.kp[l].transpose(-1, -2)) * self.scale          # [N, kvh, B*g, S]
+            # generated part: per hypothesis
+            qm = q.view(M, d.kv_heads, g, d.head_dim)
+            sg = torch.matmul(qm, kg[l, :, :, :t + 1].transpose(-1, -2)) * self.scale  # [M, kvh, g, t+1]
+            sp = sp.view(N, d.kv_heads, B, g, S).permute(0, 2, 1, 3, 4).reshape(M, d.kv_heads, g, S)
+            p = torch.softmax(torch.cat((sp, sg), dim=-1).float(), dim=-1).to(self.dtype)
+            pp, pg = p[..., :S], p[..., S:]
+            ppn = pp.view(N, B, d.kv_heads, g, S).permute(0, 2, 1, 3, 4).reshape(N, d.kv_heads, B * g, S)
+            op = torch.matmul(ppn, self.vp[l]).view(N, d.kv_heads, B, g, d.head_dim).permute(0, 2, 1, 3, 4)
+            og = torch.matmul(pg, vg[l, :, :, :t + 1])                                   # [M, kvh, g, hd]
+            a = (op.reshape(M, d.kv_heads, g, d.head_dim) + og).reshape(M, d.heads * d.head_dim)
+            x = x + F.linear(a, self.w[f"{l}.o"])
+            x = x + self._mlp(l, _rms(x, self.w[f"{l}.ln2"], d.rms_eps))
+        x = _rms(x, self.w["norm"], d.rms_eps)
+        self.t = t + 1
+        return F.linear(x, self.w["lm_head.w"], self.w["lm_head.b"]).float()
+
+    # ------------------------------------------------------------------ glue for NSDecoder.decode_batch
+    def step_fn_batched(self):
+        """Callable for `NSDecoder.decode_batch(..., needs_ids=False)`: reads the scorer's back-pointers and
+        tokens of the previous step from the workspace."""
+        base = (torch.arange(self.N, device=self.device) * self.B).repeat_interleave(self.B)
+
+        def fn(ids, lens, ws):
+            t = ws.steps_run
+            if t == 0:
+                tok = torch.full((self.N * self.B,), 37, dtype=torch.int64, device=self.device)   # BOS
+                return self.step(tok, None)
+            tok = ws.token[t - 1, :self.N * self.B].long()
+            tok = torch.where(tok >= self.d.vocab, torch.zeros_like(tok), tok)     # carried / absent slots: any id
+            parent = base + ws.backptr[t - 1, :self.N * self.B].long().clamp_(max=self.B - 1)
+            return self.step(tok, parent)
+        return fn
