@@ -155,17 +155,30 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const int B = a.B;
     bool act = ull < (long long)a.N;
     const int u = act ? (int)ull : 0;
-    const uint32_t um = act ? a.in.utt[u] : NSD_U_DONE;
+    // The hypothesis records are requested together with the utterance word, for every slot of the beam
+    // (slots past the current beam count hold stale values, which are never used): one memory round trip
+    // instead of two.  Both the early-out below and the step proper consume them.
+    const bool slot = act && gl < B;
+    const size_t si = (size_t)u * B + (slot ? gl : 0);
+    uint32_t um = NSD_U_DONE, ld_meta = 0, ld_node = 0, ld_ctx_id = 0, ld_ctxe_id = 0;
+    double ld_score = 0.0, ld_G0 = 0.0, ld_Ge = 0.0;
+    uint64_t ld_ctx = 0, ld_hist = 0;
+    if (act) um = a.in.utt[u];
+    if (slot) {
+        ld_meta = a.in.meta[si];   ld_node = a.in.node[si];
+        ld_ctx_id = a.in.ctx_id[si]; ld_ctxe_id = a.in.ctxe_id[si];
+        ld_score = a.in.score[si]; ld_G0 = a.in.lmsum[si]; ld_Ge = a.in.lmsum_e[si];
+        ld_ctx = a.in.ctx[si];     ld_hist = a.in.hist[si];
+    }
     const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
 
     if (act && (um & NSD_U_DONE)) {
         if (a.in.score != a.out.score) {
             if (gl < nbeams) {
-                const size_t i = (size_t)u * B + gl;
-                a.out.score[i] = a.in.score[i]; a.out.lmsum[i] = a.in.lmsum[i]; a.out.lmsum_e[i] = a.in.lmsum_e[i];
-                a.out.ctx[i] = a.in.ctx[i];     a.out.hist[i] = a.in.hist[i];
-                a.out.ctx_id[i] = a.in.ctx_id[i]; a.out.ctxe_id[i] = a.in.ctxe_id[i];
-                a.out.node[i] = a.in.node[i];   a.out.meta[i] = a.in.meta[i];
+                a.out.score[si] = ld_score; a.out.lmsum[si] = ld_G0; a.out.lmsum_e[si] = ld_Ge;
+                a.out.ctx[si] = ld_ctx;     a.out.hist[si] = ld_hist;
+                a.out.ctx_id[si] = ld_ctx_id; a.out.ctxe_id[si] = ld_ctxe_id;
+                a.out.node[si] = ld_node;   a.out.meta[si] = ld_meta;
             }
             if (gl == 0) a.out.utt[u] = um;
         }
@@ -197,15 +210,15 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     if (gl == 0) L.total[0] = 0;
     if (act && gl < nbeams) {
         const size_t i = (size_t)u * B + gl;
-        const uint32_t meta = a.in.meta[i];
-        const uint32_t node = a.in.node[i];
-        const uint32_t ctx_id = a.in.ctx_id[i];
-        const uint32_t ctxe_id = a.in.ctxe_id[i];
-        const double score = a.in.score[i];
-        const double G0 = a.in.lmsum[i];
-        const double Ge = a.in.lmsum_e[i];
-        const uint64_t ctx = a.in.ctx[i];
-        const uint64_t hist = a.in.hist[i];
+        const uint32_t meta = ld_meta;
+        const uint32_t node = ld_node;
+        const uint32_t ctx_id = ld_ctx_id;
+        const uint32_t ctxe_id = ld_ctxe_id;
+        const double score = ld_score;
+        const double G0 = ld_G0;
+        const double Ge = ld_Ge;
+        const uint64_t ctx = ld_ctx;
+        const uint64_t hist = ld_hist;
         const uint32_t flags = meta & 0xffu;
         const int glen = (int)(meta >> 8);
         my_live = !(flags & NSD_F_FINISHED);
