@@ -83,6 +83,7 @@ NSD_D GroupLds carve(unsigned char *base, int B, uint32_t cap, bool with_score)
 {
     GroupLds w;
     unsigned char *p = base;
+    B = (B + 1) & ~1;                              // keeps cKey / sKey 16-byte aligned (paired key reads)
     w.bScore = (double *)p;   p += 8 * B;
     w.bG     = (double *)p;   p += 8 * B;
     w.bGe    = (double *)p;   p += 8 * B;
@@ -130,7 +131,7 @@ static size_t nsd_step_lds_per_utt(int B, int G, int variant, uint32_t *cap_out)
     if (cap < 10u * (uint32_t)B) cap = 10u * (uint32_t)B;
     if (cap < 6u * (uint32_t)G) cap = 6u * (uint32_t)G;
     cap = (cap + 1u) & ~1u;
-    size_t bytes = (size_t)B * BEAM_BYTES + (size_t)cap * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) +
+    size_t bytes = (size_t)((B + 1) & ~1) * BEAM_BYTES + (size_t)cap * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) +
                    (size_t)2 * G * 12 + (size_t)(G / 8) * NSD_V * 4 + 16;
     bytes = (bytes + 15) & ~(size_t)15;
     if (cap_out) *cap_out = cap;
@@ -347,8 +348,73 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         const double *keys = L.cKey;
         bool compacted = false, full_scan = false;
         // ---- threshold: at most fcap survivors (one per lane when the beam allows it) ----
-        const uint32_t fcap = (2u * (uint32_t)nsel <= (uint32_t)G) ? (uint32_t)G : 2u * (uint32_t)G;
-        if (__ballot(want && C > fcap) != 0) {
+        // two candidates per lane are ranked directly: a search only pays beyond that
+        const uint32_t fcap = 2u * (uint32_t)G;
+        constexpr int KMAX = 4;                    // keys a lane keeps in registers during the search
+        if (__ballot(want && C > fcap) != 0 && chunks <= (uint32_t)KMAX) {
+            // The search runs on registers: lane gl holds candidates gl, gl + G, ...; a pivot is broadcast
+            // from the lane that owns it and counted with one compare + ballot per held key.
+            bool searching = want && C > fcap;
+            double kk[KMAX];
+            bool kv[KMAX];
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) {
+                const uint32_t i = (uint32_t)c * G + gl;
+                kv[c] = searching && i < C;
+                kk[c] = kv[c] ? L.cKey[i] : 0.0;
+            }
+            double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
+            bool ok = false;
+            for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
+                bool have = false;
+                double pivot = 0.0;
+                const int rot = (it * 7 + 3) % G;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    const uint64_t gb = gballot(searching && !have && kv[c] && kk[c] > lo && kk[c] < hi);
+                    const bool pick = gb != 0 && searching && !have;
+                    int src = lane;
+                    if (pick) {
+                        const uint64_t hiPart = gb & ~((1ull << rot) - 1ull);
+                        src = gshift + __ffsll((long long)(hiPart ? hiPart : gb)) - 1;
+                    }
+                    double cand;
+                    if (UPW == 1) {
+                        // one utterance per wave: the owner lane is the same for all lanes
+                        const int sl = __builtin_amdgcn_readfirstlane(src);
+                        const long long bits = __double_as_longlong(kk[c]);
+                        const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, sl);
+                        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)bits >> 32), sl);
+                        cand = __longlong_as_double((long long)(((uint64_t)bhi << 32) | blo));
+                    } else {
+                        cand = __shfl(kk[c], src);
+                    }
+                    if (pick) { pivot = cand; have = true; }
+                }
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    cnt += (uint32_t)__popcll(gballot(searching && have && kv[c] && kk[c] >= pivot));
+                if (searching) {
+                    if (!have) { full_scan = true; searching = false; }       // clustered / tied keys
+                    else if (cnt < (uint32_t)nsel) hi = pivot;
+                    else if (cnt > fcap) lo = pivot;
+                    else { ok = true; tau = pivot; F = cnt; searching = false; }
+                }
+            }
+            if (searching) { full_scan = true; searching = false; }
+            // compact the survivors
+            uint32_t n = 0;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) {
+                const bool pred = ok && kv[c] && kk[c] >= tau;
+                const uint64_t gb = gballot(pred);
+                if (pred) { const uint32_t sidx = n + gprefix(gb); L.sKey[sidx] = kk[c]; L.sIdx[sidx] = (uint32_t)c * G + gl; }
+                n += (uint32_t)__popcll(gb);
+            }
+            nsd_wave_sync();
+            if (ok) { keys = L.sKey; compacted = true; }
+        } else         if (__ballot(want && C > fcap) != 0) {
             bool searching = want && C > fcap;
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
             bool ok = false;
@@ -411,11 +477,35 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 // one candidate per lane; reads past a group's F compare against that group's own stale
                 // buffer entries and are discarded by the q < F test
                 if (UPW == 1) {
-#pragma unroll 4
-                    for (uint32_t q = 0; q < Fmax; ++q) r0 += (keys[q] > k0) ? 1u : 0u;
+                    // two keys per LDS read, eight reads in flight
+                    const double2 *k2 = reinterpret_cast<const double2 *>(keys);
+                    const uint32_t pairs = Fmax >> 1;
+#pragma unroll 8
+                    for (uint32_t q = 0; q < pairs; ++q) {
+                        const double2 k = k2[q];
+                        r0 += (k.x > k0) ? 1u : 0u;
+                        r0 += (k.y > k0) ? 1u : 0u;
+                    }
+                    if (Fmax & 1u) r0 += (keys[Fmax - 1] > k0) ? 1u : 0u;
                 } else {
 #pragma unroll 4
                     for (uint32_t q = 0; q < Fmax; ++q) r0 += (q < F && keys[q] > k0) ? 1u : 0u;
+                }
+            } else if (UPW == 1) {
+                const double2 *k2 = reinterpret_cast<const double2 *>(keys);
+                const uint32_t pairs = Fmax >> 1;
+#pragma unroll 4
+                for (uint32_t q = 0; q < pairs; ++q) {
+                    const double2 k = k2[q];
+                    r0 += (k.x > k0) ? 1u : 0u;
+                    r1 += (k.x > k1) ? 1u : 0u;
+                    r0 += (k.y > k0) ? 1u : 0u;
+                    r1 += (k.y > k1) ? 1u : 0u;
+                }
+                if (Fmax & 1u) {
+                    const double k = keys[Fmax - 1];
+                    r0 += (k > k0) ? 1u : 0u;
+                    r1 += (k > k1) ? 1u : 0u;
                 }
             } else {
 #pragma unroll 2
