@@ -51,6 +51,10 @@ for t in range(40):
                 "pass0: emit": s[act, 8] - s[act, 7], "final select: threshold": s[act, 9] - s[act, 3],
                 "final select: rank": s[act, 4] - s[act, 9]}
         tot = (s[act, 5] - s[act, 0]).astype(np.float64)
+        t0 = s[act, 0].min()
+        pct = np.percentile(tot, [50, 90, 99, 100])
+        print(f"   wave duration p50/p90/p99/max {pct.round()}  first start..last start {int(s[act,0].max()-t0)}  "
+              f"last end {int(s[act,5].max()-t0)}  phase max: " + "  ".join(f"{n.split('(')[0]} {d[:,i].max():.0f}" for i, n in enumerate(names)))
         span = (s[act, 5].max() - s[act, 0].min())
         print(f"step {t:2d}: active waves {act.sum():5d}  kernel {e0.elapsed_time(e1)*1e3:6.1f} us  "
               f"wave mean {tot.mean():8.0f} ticks  span {span} ticks | " + "  ".join(f"{n} {d[:,i].mean():7.0f}" for i, n in enumerate(names)) +
