@@ -51,6 +51,12 @@ for t in range(40):
                 "pass0: emit": s[act, 8] - s[act, 7], "final select: threshold": s[act, 9] - s[act, 3],
                 "final select: rank": s[act, 4] - s[act, 9]}
         tot = (s[act, 5] - s[act, 0]).astype(np.float64)
+        Cc = s[act, 10].astype(np.int64)
+        for lo_, hi_ in ((0, 64), (64, 96), (96, 128), (128, 160), (160, 1000)):
+            m = (Cc > lo_) & (Cc <= hi_)
+            if m.any():
+                print(f"      C in ({lo_},{hi_}]: {m.sum():5d} waves, duration mean {tot[m].mean():7.0f} max {tot[m].max():7.0f} | "
+                      + "  ".join(f"{n.split('(')[0]} {d[m, i].mean():6.0f}" for i, n in enumerate(names)))
         t0 = s[act, 0].min()
         pct = np.percentile(tot, [50, 90, 99, 100])
         print(f"   wave duration p50/p90/p99/max {pct.round()}  first start..last start {int(s[act,0].max()-t0)}  "

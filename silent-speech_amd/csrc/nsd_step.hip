@@ -37,8 +37,10 @@ constexpr uint32_t SEL_NONE = 0xFFFFFFFFu;
 // phase boundaries into a buffer of its own that no other code reads.
 __device__ unsigned long long *g_nsd_stamps = nullptr;
 #define NSD_STAMP(k) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NSD_STAMP_VALUE(k, v) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 16 + (k)] = (unsigned long long)(v); } while (0)
 #else
 #define NSD_STAMP(k) do { } while (0)
+#define NSD_STAMP_VALUE(k, v) do { } while (0)
 #endif
 
 // candidate info word: tok[0:6) kind[6:8) order[8:20) (= parent*64 + w)
@@ -679,6 +681,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const int nsel = (int)C < B ? (int)C : B;
     select_top(act, nsel);
     NSD_STAMP(4);
+    NSD_STAMP_VALUE(10, C);
+    NSD_STAMP_VALUE(11, nlive);
 
     // ---------------- write the surviving hypotheses ----------------
     bool fin = true;
