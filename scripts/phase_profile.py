@@ -23,12 +23,14 @@ import ctypes as C
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "U"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+BEAM = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+OPEN = len(sys.argv) > 4 and sys.argv[4] == "open"
 dev = torch.device("cuda", 0)
-words = S.make_lexicon(200, 0)
+words = S.make_lexicon(100000, 1, S.BASE_CHARS[:36], 2, 12) if OPEN else S.make_lexicon(200, 0)
 lm = NgramCounts(5, floor_vsz=(variant == "U")).fit(S.make_sentences(words, 20000, 1))
 tg, tl = S.pack_targets(S.make_sentences(words, N, 1000, 3, 7))
 tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
-dec = NSDecoder(DeviceTables.from_words(words, lm), 16, 64, variant=variant, lm_weight=0.05, word_bonus=0.35)
+dec = NSDecoder(DeviceTables.from_words(words, lm), BEAM, 64, variant=variant, lm_weight=0.05, word_bonus=0.35)
 ws = dec.workspace(N)
 stamps = torch.zeros(N, 16, dtype=torch.int64, device=dev)   # one row per wave (a wave carries 64/G utterances)
 L = lib.load()
@@ -52,6 +54,8 @@ for t in range(40):
                 "final select: rank": s[act, 4] - s[act, 9]}
         tot = (s[act, 5] - s[act, 0]).astype(np.float64)
         Cc = s[act, 10].astype(np.int64)
+        print(f"      per wave: candidates mean {Cc.mean():.0f} max {Cc.max()}  live {s[act, 11].mean():.1f}  tie re-ranks {s[act, 12].mean():.3f}  "
+              f"threshold iterations {s[act, 13].mean():.2f}  prunes {s[act, 14].mean():.2f}  LDS-path searches {s[act, 15].mean():.2f}")
         for lo_, hi_ in ((0, 64), (64, 96), (96, 128), (128, 160), (160, 1000)):
             m = (Cc > lo_) & (Cc <= hi_)
             if m.any():

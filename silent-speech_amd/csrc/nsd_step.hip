@@ -270,6 +270,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     NSD_STAMP(1);
 
     uint32_t C = 0;                               // candidates in this utterance's buffer (uniform in the group)
+#ifdef NSD_STAMPS
+    uint32_t dbg_redo = 0, dbg_iters = 0, dbg_prunes = 0, dbg_slowthr = 0;
+#define NSD_COUNT(x) do { ++(x); } while (0)
+#else
+#define NSD_COUNT(x) do { } while (0)
+#endif
     bool err_topk = false;
 
     auto emit = [&](bool pred, float lp, uint32_t info) {
@@ -368,11 +374,13 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
             bool ok = false;
             for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
+                NSD_COUNT(dbg_iters);
                 bool have = false;
                 double pivot = 0.0;
                 const int rot = (it * 7 + 3) % G;
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) {
+                    if ((uint32_t)c >= chunks) break;
                     const uint64_t gb = gballot(searching && !have && kv[c] && kk[c] > lo && kk[c] < hi);
                     const bool pick = gb != 0 && searching && !have;
                     int src = lane;
@@ -395,8 +403,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 }
                 uint32_t cnt = 0;
 #pragma unroll
-                for (int c = 0; c < KMAX; ++c)
+                for (int c = 0; c < KMAX; ++c) {
+                    if ((uint32_t)c >= chunks) break;
                     cnt += (uint32_t)__popcll(gballot(searching && have && kv[c] && kk[c] >= pivot));
+                }
                 if (searching) {
                     if (!have) { full_scan = true; searching = false; }       // clustered / tied keys
                     else if (cnt < (uint32_t)nsel) hi = pivot;
@@ -409,6 +419,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             uint32_t n = 0;
 #pragma unroll
             for (int c = 0; c < KMAX; ++c) {
+                if ((uint32_t)c >= chunks) break;
                 const bool pred = ok && kv[c] && kk[c] >= tau;
                 const uint64_t gb = gballot(pred);
                 if (pred) { const uint32_t sidx = n + gprefix(gb); L.sKey[sidx] = kk[c]; L.sIdx[sidx] = (uint32_t)c * G + gl; }
@@ -420,7 +431,9 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             bool searching = want && C > fcap;
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
             bool ok = false;
+            NSD_COUNT(dbg_slowthr);
             for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
+                NSD_COUNT(dbg_iters);
                 // pivot: first key inside (lo, hi), starting at a lane that rotates with the iteration
                 bool have = false;
                 double pivot = 0.0;
@@ -528,6 +541,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         const bool hole = want && gl < nsel && L.sel[gl] == SEL_NONE;
         const bool redo = want && (full_scan || claimed != (uint32_t)nsel || gballot(hole) != 0);
         if (__ballot(redo) != 0) {
+            NSD_COUNT(dbg_redo);
             if (redo && gl < B) L.sel[gl] = SEL_NONE;
             nsd_wave_sync();
             const uint32_t Cmax = wave_max(redo ? C : 0u);
@@ -553,6 +567,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // prune the buffer of the groups with `over` to its top-B, moved to the front
     auto prune = [&](bool over) {
         const int keep = (int)C < B ? (int)C : B;
+        NSD_COUNT(dbg_prunes);
         select_top(over, keep);
         uint32_t info = 0;
         double key = 0.0, sc = 0.0;
@@ -683,6 +698,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     NSD_STAMP(4);
     NSD_STAMP_VALUE(10, C);
     NSD_STAMP_VALUE(11, nlive);
+#ifdef NSD_STAMPS
+    NSD_STAMP_VALUE(12, dbg_redo);
+    NSD_STAMP_VALUE(13, dbg_iters);
+    NSD_STAMP_VALUE(14, dbg_prunes);
+    NSD_STAMP_VALUE(15, dbg_slowthr);
+#endif
 
     // ---------------- write the surviving hypotheses ----------------
     bool fin = true;
