@@ -55,7 +55,8 @@ for t in range(40):
         tot = (s[act, 5] - s[act, 0]).astype(np.float64)
         Cc = s[act, 10].astype(np.int64)
         print(f"      per wave: candidates mean {Cc.mean():.0f} max {Cc.max()}  live {s[act, 11].mean():.1f}  tie re-ranks {s[act, 12].mean():.3f}  "
-              f"threshold iterations {s[act, 13].mean():.2f}  prunes {s[act, 14].mean():.2f}  LDS-path searches {s[act, 15].mean():.2f}")
+              f"threshold iterations {s[act, 13].mean():.2f}  prunes {s[act, 14].mean():.2f}  LDS-path searches {s[act, 15].mean():.2f}  "
+              f"inside passes: scoring before prunes {s[act, 7].mean():.0f}  prunes {s[act, 8].mean():.0f} ticks (slots 7/8 hold these totals)")
         for lo_, hi_ in ((0, 64), (64, 96), (96, 128), (128, 160), (160, 1000)):
             m = (Cc > lo_) & (Cc <= hi_)
             if m.any():

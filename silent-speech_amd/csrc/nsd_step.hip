@@ -272,9 +272,14 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     uint32_t C = 0;                               // candidates in this utterance's buffer (uniform in the group)
 #ifdef NSD_STAMPS
     uint32_t dbg_redo = 0, dbg_iters = 0, dbg_prunes = 0, dbg_slowthr = 0;
+    unsigned long long dbg_t_prune = 0, dbg_t_score = 0, dbg_t0 = 0;
+#define NSD_TIC() do { dbg_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define NSD_TOC(acc) do { (acc) += __builtin_amdgcn_s_memtime() - dbg_t0; } while (0)
 #define NSD_COUNT(x) do { ++(x); } while (0)
 #else
 #define NSD_COUNT(x) do { } while (0)
+#define NSD_TIC() do { } while (0)
+#define NSD_TOC(acc) do { } while (0)
 #endif
     bool err_topk = false;
 
@@ -636,9 +641,13 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             add = __shfl(add, gshift);
             const bool over = act && C + add > CAP;
             if (__ballot(over) != 0) {
+                NSD_TIC();
                 if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored); nsd_wave_sync(); }
+                NSD_TOC(dbg_t_score);
                 scored = C;
+                NSD_TIC();
                 prune(over);
+                NSD_TOC(dbg_t_prune);
                 if (over) scored = C;
             }
         }
@@ -703,6 +712,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     NSD_STAMP_VALUE(13, dbg_iters);
     NSD_STAMP_VALUE(14, dbg_prunes);
     NSD_STAMP_VALUE(15, dbg_slowthr);
+    NSD_STAMP_VALUE(8, dbg_t_prune);
+    NSD_STAMP_VALUE(7, dbg_t_score);
 #endif
 
     // ---------------- write the surviving hypotheses ----------------
