@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""NS-decode throughput benchmark (BASELINE.json metric).
+"""NS-decode throughput benchmark: NS-decoded characters per second.
 
 One "step" = one full NS decode of the resident batch: up to T_max scorer
 launches (nsd_step) fed by the synthetic integer-hash AR head (nsd_synth_logits,
@@ -8,7 +8,7 @@ utterance has finished, back-trace, and - with more than one rank - the final
 gather of token ids.  Inputs (tables, planted targets) are resident in HBM
 before the timed region starts.
 
-Default workload (N = 1): BASELINE.json configs[1] - 4096 synthetic utterances,
+Default workload (N = 1): the benchmark's second configuration - 4096 synthetic utterances,
 beam 16, closed 200-word template lexicon trie + character 5-gram LM, decoded
 by the copy of the NS decoder that inference_emg_llm.py itself calls (variant
 I, inference_emg_llm.py:222-300: no EOS option, so every utterance runs all

@@ -1,4 +1,4 @@
-"""CTC greedy proposal + LM rerank (BASELINE configs[3]) timing: HIP events around nsd_ctc_greedy."""
+"""CTC greedy proposal + LM rerank (the CTC + rerank benchmark configuration) timing: HIP events around nsd_ctc_greedy."""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

@@ -385,7 +385,7 @@ def test_exact_score_ties_follow_the_canonical_order(dev):
 
 
 def test_ctc_proposal_and_lm_rerank_pipeline(dev):
-    """BASELINE configs[3]: AR decode (variant I, as inference_emg_llm.py calls it) + CTC greedy proposal +
+    """The CTC + rerank configuration: AR decode (variant I, as inference_emg_llm.py calls it) + CTC greedy proposal +
     LM rerank, all on device, against the Python restatement of inference_emg_llm.py:436-464 without
     postprocess."""
     from silent_speech_amd.decoder import DeviceTables, NSDecoder, ctc_greedy_batch, rerank_lm_batch
