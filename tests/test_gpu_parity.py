@@ -513,3 +513,49 @@ def test_lm_regularizer_matches_reference_values():
     # same bits on a second call (fixed-order reduction)
     loss2 = ns_lm_regularizer(x.detach(), None, torch.from_numpy(out_ids).to(dev), tab)
     assert float(loss2) == float(loss.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["I", "U"])
+def test_full_size_batch_properties(variant):
+    """The benchmark's full batch (4096 utterances, beam 16, 5-gram, 64 steps), checked through properties
+    that do not need the CPU checker on every utterance: a second decode gives the same bits; a slice of the
+    batch decoded on its own gives the same ids / lengths / fp64 scores as inside the batch (utterances are
+    independent); the lanes-per-utterance knob changes nothing; and a 48-utterance sample equals the C checker."""
+    from silent_speech_amd import synthetic as S
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    from silent_speech_amd.tables import NgramCounts
+    dev = torch.device("cuda", 0)
+    N, B, T, seed, margin = 4096, 16, 64, 20260403, 60.0
+    words = S.make_lexicon(200, 0)
+    corpus = S.make_sentences(words, 20000, 1)
+    targets = S.make_sentences(words, N, 1000, 3, 7)
+    tg, tl = S.pack_targets(targets)
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    floor = variant == "U"
+    tables = DeviceTables.from_words(words, NgramCounts(5, floor_vsz=floor).fit(corpus))
+
+    def run(lo, hi, lanes=0):
+        dec = NSDecoder(tables, B, T, variant=variant, lm_weight=0.05, oov_penalty=1.0, lanes_per_utt=lanes)
+        ids, lens, sc = dec.decode_synth_native(tgd[lo:hi].contiguous(), tld[lo:hi].contiguous(), base_seed=seed,
+                                                margin=margin, utt0=lo)
+        torch.cuda.synchronize()
+        return ids.cpu().numpy().copy(), lens.cpu().numpy().copy(), sc.cpu().numpy().copy()
+
+    ids, lens, sc = run(0, N)
+    ids2, lens2, sc2 = run(0, N)
+    assert (ids == ids2).all() and (lens == lens2).all() and (sc.view(np.int64) == sc2.view(np.int64)).all()
+    for lo, hi, lanes in ((1000, 1064, 0), (4000, 4096, 0), (0, N, 32), (2048, 2560, 16)):
+        i3, l3, s3 = run(lo, hi, lanes)
+        assert (l3 == lens[lo:hi]).all(), (lo, hi, lanes)
+        assert (i3 == ids[lo:hi]).all(), (lo, hi, lanes)
+        assert (s3.view(np.int64) == sc[lo:hi].view(np.int64)).all(), (lo, hi, lanes)
+    # a sample against the CPU checker (which numbers utterances from 0: take the first ones)
+    n = 48
+    ref = cbind.Model(words, corpus, 5, floor).decode_synth(
+        variant=variant, beam=B, max_new_tokens=T, beta=0.05, gamma=1.0, kappa=0.0, margin=margin, base_seed=seed,
+        targets=tg[:n], target_lens=tl[:n], trace=False)
+    assert (ref["lens"] == lens[:n]).all()
+    for u in range(n):
+        assert (ref["ids"][u, :lens[u]] == ids[u, :lens[u]]).all(), u
+        assert float(ref["scores"][u]).hex() == float(sc[u]).hex(), u
