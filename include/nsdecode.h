@@ -288,6 +288,18 @@ int nsd_lm_prior_ce_grad(const NsdTables *t, const float *logits, const int64_t 
                          int32_t V, int32_t form, const double *stats, const float *grad_out, float *grad_logits,
                          void *stream);
 
+/* Beam re-ordering of a key/value cache after a scorer step: hypothesis m of the new beam continues
+ * hypothesis parent(m) of the old one, so the cached rows of the generated positions follow it.  The
+ * reference keeps no cache (EMGTextModel.step re-runs the whole sequence, inference_emg_llm.py:83-88); this
+ * is the copy a KV-cached batched step needs between two nsd_step launches.
+ *   src, dst  device [L, M, H, T, row_bytes] (layers, hypotheses M = N*B, kv heads, positions, bytes of one
+ *             head row); distinct buffers; row_bytes a multiple of 16
+ *   backptr   device [M] u8: the scorer's back-pointers of the step (index inside the utterance's beam),
+ *             parent(m) = (m / B) * B + backptr[m]
+ *   t         positions 0..t-1 are copied: dst[l, m, h, i] = src[l, parent(m), h, i] */
+int nsd_kv_reorder(const void *src, void *dst, const uint8_t *backptr, int32_t L, int32_t M, int32_t B, int32_t H,
+                   int32_t T, int32_t t, int32_t row_bytes, void *stream);
+
 /* Row-wise deterministic fp32 log-softmax, the one nsd_step applies
  * (F.log_softmax at scripts/ns_utils.py:227).  x, out device [rows, V]. */
 int nsd_log_softmax(const float *x, int32_t rows, int32_t V, float *out, void *stream);

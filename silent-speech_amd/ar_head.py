@@ -158,19 +158,34 @@ class TorchLlamaStep:
 
     # ------------------------------------------------------------------ one decode step
     @torch.no_grad()
-    def step(self, tokens: torch.Tensor, parent: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def step(self, tokens: torch.Tensor, parent: Optional[torch.Tensor] = None,
+             backptr: Optional[torch.Tensor] = None) -> torch.Tensor:
         """tokens [N*B] int64: the last token of every hypothesis (BOS at the first step); parent [N*B] int64:
         global index of the hypothesis each one extends (the scorer's back-pointer + u*B), None at the first
-        step.  Returns float32 logits [N*B, vocab]."""
+        step; alternatively backptr [N*B] uint8, the scorer's back-pointers themselves, which on the GPU are
+        applied to the cache by one nsd_kv_reorder launch per tensor.  Returns float32 logits [N*B, vocab]."""
         d, t, S, N, B = self.d, self.t, self.S, self.N, self.B
         M = N * B
         if t >= self.T:
             raise ValueError("all max_new_tokens steps already ran")
-        reorder = parent is not None and t > 0
+        if backptr is not None and t > 0 and self.device.type != "cuda":
+            base = (torch.arange(N, device=self.device) * B).repeat_interleave(B)
+            parent = base + backptr.long().clamp(max=B - 1)
+            backptr = None
+        reorder = parent is not None and t > 0 and backptr is None
         kg_old, vg_old = self.kg[self.cur], self.vg[self.cur]
-        if reorder:
+        if reorder or (backptr is not None and t > 0):
             self.cur = 1 - self.cur
         kg, vg = self.kg[self.cur], self.vg[self.cur]
+        if backptr is not None and t > 0:
+            # generated keys/values follow their hypotheses: one batched copy of the first t positions
+            from . import lib as _lib
+            Lh = _lib.load()
+            row_bytes = d.head_dim * kg.element_size()
+            st = torch.cuda.current_stream().cuda_stream
+            for src, dst in ((kg_old, kg), (vg_old, vg)):
+                _lib.check(Lh.nsd_kv_reorder(src.data_ptr(), dst.data_ptr(), backptr.data_ptr(), d.layers, M, B,
+                                             d.kv_heads, max(self.T, 1), t, row_bytes, st), "nsd_kv_reorder")
         x = F.embedding(tokens, self.w["char_embed"])                     # [M, hidden]
         cos, sin = self._cos_sin(torch.full((1,), S + t, device=self.device))
         g = d.heads // d.kv_heads
@@ -207,8 +222,6 @@ class TorchLlamaStep:
     def step_fn_batched(self):
         """Callable for `NSDecoder.decode_batch(..., needs_ids=False)`: reads the scorer's back-pointers and
         tokens of the previous step from the workspace."""
-        base = (torch.arange(self.N, device=self.device) * self.B).repeat_interleave(self.B)
-
         def fn(ids, lens, ws):
             t = ws.steps_run
             if t == 0:
@@ -216,6 +229,5 @@ class TorchLlamaStep:
                 return self.step(tok, None)
             tok = ws.token[t - 1, :self.N * self.B].long()
             tok = torch.where(tok >= self.d.vocab, torch.zeros_like(tok), tok)     # carried / absent slots: any id
-            parent = base + ws.backptr[t - 1, :self.N * self.B].long().clamp_(max=self.B - 1)
-            return self.step(tok, parent)
+            return self.step(tok, backptr=ws.backptr[t - 1, :self.N * self.B])
         return fn

@@ -482,6 +482,48 @@ extern "C" int nsd_rerank_gather(const float *logits, const uint8_t *target, con
 }
 
 // ---------------------------------------------------------------------
+// beam re-ordering of a KV cache: a batched copy of L*M*H chunks of t*row_bytes contiguous bytes, 16 bytes per
+// lane; chunks are dealt to waves so that consecutive waves read consecutive heads of one source hypothesis
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nsd_kv_reorder_kernel(const uint4 *src, uint4 *dst, const uint8_t *backptr, uint32_t M, uint32_t B, uint32_t H,
+                      uint32_t chunk_stride /* uint4 per (l, m, h) */, uint32_t chunk_len /* uint4 to copy */,
+                      unsigned long long n_chunks)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= n_chunks) return;
+    const uint32_t h = (uint32_t)(wave % H);
+    const unsigned long long lm = wave / H;
+    const uint32_t m = (uint32_t)(lm % M);
+    const unsigned long long l = lm / M;
+    uint32_t bp = backptr[m];
+    if (bp >= B) bp = 0;                                   // slots the beam does not use: any in-range source
+    const uint32_t pm = (m / B) * B + bp;
+    const uint4 *s = src + ((l * M + pm) * H + h) * (unsigned long long)chunk_stride;
+    uint4 *d = dst + ((l * M + m) * H + h) * (unsigned long long)chunk_stride;
+    for (uint32_t i = lane; i < chunk_len; i += 64) d[i] = s[i];
+}
+
+extern "C" int nsd_kv_reorder(const void *src, void *dst, const uint8_t *backptr, int32_t L, int32_t M, int32_t B,
+                              int32_t H, int32_t T, int32_t t, int32_t row_bytes, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (L < 0 || M < 0 || H < 1 || T < 0 || t < 0 || t > T || row_bytes < 16 || (row_bytes & 15) || (M % B) != 0)
+        return NSD_E_SIZE;
+    if (L == 0 || M == 0 || t == 0) return NSD_OK;
+    if (!src || !dst || !backptr || src == dst) return NSD_E_NULL;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15u) return NSD_E_SIZE;
+    const unsigned long long n_chunks = (unsigned long long)L * M * H;
+    const unsigned long long stride = (unsigned long long)T * row_bytes / 16, len = (unsigned long long)t * row_bytes / 16;
+    if (stride > 0xFFFFFFFFull || (n_chunks + 3) / 4 > 0x7FFFFFFFull) return NSD_E_SIZE;
+    hipLaunchKernelGGL(nsd_kv_reorder_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4 *)src, (uint4 *)dst, backptr, (uint32_t)M, (uint32_t)B, (uint32_t)H,
+                       (uint32_t)stride, (uint32_t)len, n_chunks);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------
 // synthetic logits: one thread per 16-byte quarter-decade of a row (10 threads per row), so that a wave
 // writes 1 KB of consecutive bytes with one dwordx4 store per lane
 // ---------------------------------------------------------------------

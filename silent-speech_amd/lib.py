@@ -55,7 +55,7 @@ class BeamStatePtrs(C.Structure):
 EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "nsd_tables_destroy",
            "nsd_tables_order", "nsd_state_init", "nsd_step", "nsd_backtrace", "nsd_gather_ids",
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
-           "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad"]
+           "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad", "nsd_kv_reorder"]
 
 _lib = None
 
@@ -91,6 +91,7 @@ def load():
     L.nsd_decode_synth.argtypes = [vp, C.POINTER(Params), C.POINTER(BeamStatePtrs), u64, i64, vp, vp, i32, C.c_float,
                                    vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.nsd_rerank_lm.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.nsd_kv_reorder.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.nsd_cond_dist.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.nsd_lm_prior_ce.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.nsd_lm_prior_ce_grad.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]

@@ -26,7 +26,7 @@ def _reference_step(llm, char_embed, lm_head, context, ids):
         return lm_head(h)[0]
 
 
-def _run(device):
+def _run(device, use_backptr=False):
     from silent_speech_amd.ar_head import TorchLlamaStep
     llm, char_embed, lm_head = _reference_setup()
     N, B, S, T = 3, 4, 9, 6
@@ -41,7 +41,10 @@ def _run(device):
     worst = 0.0
     for t in range(T):
         tok = torch.tensor([h[-1] for h in hist], dtype=torch.long, device=device)
-        logits = head.step(tok, parent).cpu()
+        if use_backptr and parent is not None:
+            logits = head.step(tok, backptr=(parent % B).to(torch.uint8)).cpu()      # nsd_kv_reorder on the GPU
+        else:
+            logits = head.step(tok, parent).cpu()
         for m in range(N * B):
             want = _reference_step(llm, char_embed, lm_head, context[m // B:m // B + 1], hist[m])
             worst = max(worst, float((logits[m] - want).abs().max()))
@@ -60,3 +63,30 @@ def test_cached_step_matches_full_sequence_forward_cpu():
 @pytest.mark.gpu
 def test_cached_step_matches_full_sequence_forward_gpu():
     assert _run("cuda") < 2e-4
+    assert _run("cuda", use_backptr=True) < 2e-4
+
+
+def test_backptr_form_on_cpu():
+    assert _run("cpu", use_backptr=True) < 2e-4
+
+
+@pytest.mark.gpu
+def test_kv_reorder_equals_index_select():
+    """nsd_kv_reorder against torch.index_select, bit for bit, bf16 and fp32 rows, partial position ranges."""
+    from silent_speech_amd import lib
+    Lh = lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    for dtype, L, N, B, H, T, t, hd in ((torch.bfloat16, 3, 5, 16, 8, 24, 13, 128), (torch.float32, 2, 7, 4, 2, 9, 9, 16),
+                                        (torch.bfloat16, 1, 1, 64, 1, 5, 1, 8)):
+        M = N * B
+        src = torch.randn(L, M, H, T, hd, generator=g, device=dev).to(dtype)
+        dst = torch.full_like(src, 7.0)
+        bp = torch.randint(0, B, (M,), generator=g, device=dev, dtype=torch.uint8)
+        lib.check(Lh.nsd_kv_reorder(src.data_ptr(), dst.data_ptr(), bp.data_ptr(), L, M, B, H, T, t,
+                                    hd * src.element_size(), torch.cuda.current_stream().cuda_stream), "nsd_kv_reorder")
+        parent = (torch.arange(N, device=dev) * B).repeat_interleave(B) + bp.long()
+        want = src.index_select(1, parent)[:, :, :, :t]
+        assert torch.equal(dst[:, :, :, :t], want)
+        assert bool((dst[:, :, :, t:] == 7.0).all())          # positions past t are left alone
+
