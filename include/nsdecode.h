@@ -319,8 +319,9 @@ int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int64_t utt0,
  *                    host and the loop stops once all N utterances are done
  *                    (one stream synchronisation per check); 0 = run all T
  *                    steps (finished utterances cost an early-exit wave each)
- *   step_ms   host [T] or NULL: when given, every nsd_step launch is bracketed
- *             by HIP events on `stream` and its duration in milliseconds is
+ *   step_ms   host [T] or NULL: when given, every nsd_step launch carries a pair
+ *             of HIP events that take the kernel's own start and end timestamps
+ *             and its duration in milliseconds is
  *             stored (entries of steps that did not run are set to -1); the
  *             call then ends with one stream synchronisation
  *   steps_run host [1] or NULL: number of steps enqueued

@@ -577,6 +577,11 @@ extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int6
 // ---------------------------------------------------------------------
 // native decode driver for the synthetic AR head
 // ---------------------------------------------------------------------
+int nsd_step_with_events(const NsdTables *t, const NsdParams *p, const float *logits,
+                         const NsdBeamState *in, const NsdBeamState *out,
+                         uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,
+                         int32_t N, int32_t B, int32_t V, void *stream, hipEvent_t ev0, hipEvent_t ev1);   // nsd_step.hip
+
 namespace {
 std::mutex g_ev_mutex;
 std::vector<hipEvent_t> g_events;          // grown on demand, reused by every timed decode
@@ -622,11 +627,10 @@ extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const Ns
     for (int step = 0; step < T; ++step) {
         rc = nsd_synth_logits(st, base_seed, utt0, targets, target_len, stride, margin, logits, N, B, stream);
         if (rc != 0) return rc;
-        if (step_ms) (void)hipEventRecord(g_events[2 * step], s);
-        rc = nsd_step(t, p, logits, st, st, backptr + (size_t)step * NB, token + (size_t)step * NB, nullptr,
-                      N, B, NSD_V, stream);
+        rc = nsd_step_with_events(t, p, logits, st, st, backptr + (size_t)step * NB, token + (size_t)step * NB,
+                                  nullptr, N, B, NSD_V, stream, step_ms ? g_events[2 * step] : nullptr,
+                                  step_ms ? g_events[2 * step + 1] : nullptr);
         if (rc != 0) return rc;
-        if (step_ms) (void)hipEventRecord(g_events[2 * step + 1], s);
         ran = step + 1;
         if (check_every > 0 && ran % check_every == 0 && ran < T) {
             hipError_t e = hipMemcpyAsync(g_host_done, st->done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);

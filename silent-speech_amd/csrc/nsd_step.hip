@@ -25,6 +25,7 @@
 // Restates the loop body of scripts/ns_utils.py:218-275 (variant U),
 // inference_emg_llm.py:239-297 (I) and eval_ar.py:243-313 (E) of the
 // reference; all score arithmetic is fp64 in the reference's operation order.
+#include <hip/hip_ext.h>
 #include "nsd_device.h"
 
 namespace {
@@ -800,7 +801,7 @@ extern "C" int nsd_debug_set_stamps(unsigned long long *p)
 #endif
 
 template <int G, int VARIANT>
-static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s)
+static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     constexpr int UPW = 64 / G;
     const uint32_t lds_per_wave = a.lds_per_utt * UPW;
@@ -809,25 +810,30 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
     while (waves > 1 && lds_per_wave * (uint32_t)waves > 40960u) waves >>= 1;
     const long long n_waves = ((long long)N + UPW - 1) / UPW;
     const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
-    hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves), lds_per_wave * (uint32_t)waves, s, a, p);
+    if (ev0 || ev1)      // the events take the kernel's own start / end timestamps (no marker packets in between)
+        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves),
+                              lds_per_wave * (uint32_t)waves, s, ev0, ev1, 0, a, p);
+    else
+        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves), lds_per_wave * (uint32_t)waves, s, a, p);
 }
 
 template <int VARIANT>
-static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s)
+static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int G = nsd_step_group(a.B, N, p.lanes_per_utt);
     a.lds_per_utt = (uint32_t)nsd_step_lds_per_utt(a.B, G, p.variant, &a.cap);
     switch (G) {
-    case 16: launch_gv<16, VARIANT>(a, p, N, s); break;
-    case 32: launch_gv<32, VARIANT>(a, p, N, s); break;
-    default: launch_gv<64, VARIANT>(a, p, N, s); break;
+    case 16: launch_gv<16, VARIANT>(a, p, N, s, ev0, ev1); break;
+    case 32: launch_gv<32, VARIANT>(a, p, N, s, ev0, ev1); break;
+    default: launch_gv<64, VARIANT>(a, p, N, s, ev0, ev1); break;
     }
 }
 
-extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
-                        const NsdBeamState *in, const NsdBeamState *out,
-                        uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,
-                        int32_t N, int32_t B, int32_t V, void *stream)
+// nsd_step with optional events that receive the kernel's own start and end timestamps
+int nsd_step_with_events(const NsdTables *t, const NsdParams *p, const float *logits,
+                         const NsdBeamState *in, const NsdBeamState *out,
+                         uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,
+                         int32_t N, int32_t B, int32_t V, void *stream, hipEvent_t ev0, hipEvent_t ev1)
 {
     if (!t || !p) return NSD_E_NULL;
     if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
@@ -842,9 +848,17 @@ extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *log
     a.N = N; a.B = B;
     hipStream_t s = (hipStream_t)stream;
     switch (p->variant) {
-    case NSD_VARIANT_U: launch_variant<NSD_VARIANT_U>(a, *p, N, s); break;
-    case NSD_VARIANT_I: launch_variant<NSD_VARIANT_I>(a, *p, N, s); break;
-    default:            launch_variant<NSD_VARIANT_E>(a, *p, N, s); break;
+    case NSD_VARIANT_U: launch_variant<NSD_VARIANT_U>(a, *p, N, s, ev0, ev1); break;
+    case NSD_VARIANT_I: launch_variant<NSD_VARIANT_I>(a, *p, N, s, ev0, ev1); break;
+    default:            launch_variant<NSD_VARIANT_E>(a, *p, N, s, ev0, ev1); break;
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
+                        const NsdBeamState *in, const NsdBeamState *out,
+                        uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,
+                        int32_t N, int32_t B, int32_t V, void *stream)
+{
+    return nsd_step_with_events(t, p, logits, in, out, backptr, token, mask_dbg, N, B, V, stream, nullptr, nullptr);
 }
