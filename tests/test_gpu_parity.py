@@ -559,3 +559,47 @@ def test_full_size_batch_properties(variant):
     for u in range(n):
         assert (ref["ids"][u, :lens[u]] == ids[u, :lens[u]]).all(), u
         assert float(ref["scores"][u]).hex() == float(sc[u]).hex(), u
+
+
+@pytest.mark.gpu
+def test_step_into_a_second_state_buffer_equals_in_place():
+    """nsd_step may write the new hypothesis state into other arrays than it reads (double buffering): the
+    result equals stepping in place, including utterances that are already finished (their state is copied)."""
+    import ctypes as C
+    from silent_speech_amd import lib
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder, Workspace
+    dev = torch.device("cuda", 0)
+    words = synth.make_lexicon(200, 0)
+    corpus = synth.make_sentences(words, 2000, 1)
+    targets = synth.make_sentences(words, 96, 9, 1, 3)          # short targets: variant U finishes early
+    tg, tl = _pack_targets(targets)
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    tables = DeviceTables.from_words(words, O.NgramLM(5).fit(corpus))
+    N, B, T = len(targets), 8, 40
+    dec = NSDecoder(tables, B, T, variant="U", lm_weight=0.05)
+    ids_a, lens_a, sc_a = dec.decode_synth(tgd, tld, base_seed=11, margin=30.0, check_every=0)
+    ids_a, lens_a, sc_a = ids_a.cpu().numpy().copy(), lens_a.cpu().numpy().copy(), sc_a.cpu().numpy().copy()
+
+    L = lib.load()
+    w = [Workspace(N, B, T, dev), Workspace(N, B, T, dev)]
+    dec.init(w[0])
+    st = torch.cuda.current_stream().cuda_stream
+    for t in range(T):
+        src, dst = w[t & 1], w[1 - (t & 1)]
+        lib.check(L.nsd_synth_logits(C.byref(src.ptrs), 11, 0, tgd.data_ptr(), tld.data_ptr(), tgd.shape[1], 30.0,
+                                     src.logits.data_ptr(), N, B, st), "nsd_synth_logits")
+        # back-pointers and tokens of all steps are kept in the first workspace
+        lib.check(L.nsd_step(tables.handle, C.byref(dec.params), src.logits.data_ptr(), C.byref(src.ptrs),
+                             C.byref(dst.ptrs), w[0].backptr.data_ptr() + t * N * B, w[0].token.data_ptr() + t * N * B,
+                             None, N, B, 40, st), "nsd_step")
+    last = w[T & 1]
+    out_ids = torch.zeros(N, T + 1, dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    out_sc = torch.zeros(N, dtype=torch.float64, device=dev)
+    lib.check(L.nsd_backtrace(C.byref(last.ptrs), w[0].backptr.data_ptr(), w[0].token.data_ptr(), T, N, B,
+                              out_ids.data_ptr(), out_len.data_ptr(), out_sc.data_ptr(), st), "nsd_backtrace")
+    torch.cuda.synchronize()
+    assert (out_len.cpu().numpy() == lens_a).all()
+    assert (out_ids.cpu().numpy() == ids_a).all()
+    assert (out_sc.cpu().numpy().view(np.int64) == sc_a.view(np.int64)).all()
+    assert bool((last.utt[:N] & lib.U_DONE).all())              # every utterance finished well before step 40
