@@ -99,8 +99,11 @@ NSD_D GroupLds carve(unsigned char *base, int B, uint32_t cap, bool with_score)
     w.cKey   = (double *)p;   p += 8 * (size_t)cap;
     w.cScore = (double *)p;   if (with_score) p += 8 * (size_t)cap;
     w.sKey   = (double *)p;   p += 8 * 2 * G;
-    w.cInfo  = (uint32_t *)p; p += 4 * (size_t)cap;
     w.sIdx   = (uint32_t *)p; p += 4 * 2 * G;
+    // the fall-back's row buffer (G/8 rows of 40 floats = 20 G bytes) shares the 24 G bytes of the
+    // selection's compaction arrays: the two are never live at the same time
+    w.rowbuf = (float *)w.sKey;
+    w.cInfo  = (uint32_t *)p; p += 4 * (size_t)cap;
     w.bChild = (uint32_t *)p; p += 4 * B;
     w.bLmBase = (uint32_t *)p; p += 4 * B;
     w.bMeta  = (uint32_t *)p; p += 4 * B;
@@ -110,7 +113,6 @@ NSD_D GroupLds carve(unsigned char *base, int B, uint32_t cap, bool with_score)
     w.live   = (uint32_t *)p; p += 4 * B;
     w.sel    = (uint32_t *)p; p += 4 * B;
     w.total  = (uint32_t *)p; p += 16;
-    w.rowbuf = (float *)p;
     return w;
 }
 
@@ -135,7 +137,7 @@ static size_t nsd_step_lds_per_utt(int B, int G, int variant, uint32_t *cap_out)
     if (cap < 6u * (uint32_t)G) cap = 6u * (uint32_t)G;
     cap = (cap + 1u) & ~1u;
     size_t bytes = (size_t)((B + 1) & ~1) * BEAM_BYTES + (size_t)cap * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) +
-                   (size_t)2 * G * 12 + (size_t)(G / 8) * NSD_V * 4 + 16;
+                   (size_t)2 * G * 12 + 16;
     bytes = (bytes + 15) & ~(size_t)15;
     if (cap_out) *cap_out = cap;
     return bytes;
