@@ -807,9 +807,12 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
 {
     constexpr int UPW = 64 / G;
     const uint32_t lds_per_wave = a.lds_per_utt * UPW;
-    // waves per workgroup: 4 unless that needs more than 40 KiB of LDS (4 workgroups per CU)
-    int waves = 4;
-    while (waves > 1 && lds_per_wave * (uint32_t)waves > 40960u) waves >>= 1;
+    // waves per workgroup: the count (4, 2 or 1) that lets most waves share a CU's 160 KiB of LDS
+    int waves = 4, best = 0;
+    for (int w = 4; w >= 1; w >>= 1) {
+        const int per_cu = (int)(163840u / (lds_per_wave * (uint32_t)w)) * w;
+        if (per_cu > best) { best = per_cu; waves = w; }
+    }
     const long long n_waves = ((long long)N + UPW - 1) / UPW;
     const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
     if (ev0 || ev1)      // the events take the kernel's own start / end timestamps (no marker packets in between)
