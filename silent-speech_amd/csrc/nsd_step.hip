@@ -388,7 +388,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 const int rot = (it * 7 + 3) % G;
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) {
-                    if ((uint32_t)c >= chunks) break;
+                    if ((uint32_t)c >= chunks) continue;          // uniform: chunks the buffer does not have
                     const uint64_t gb = gballot(searching && !have && kv[c] && kk[c] > lo && kk[c] < hi);
                     const bool pick = gb != 0 && searching && !have;
                     int src = lane;
@@ -412,7 +412,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 uint32_t cnt = 0;
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) {
-                    if ((uint32_t)c >= chunks) break;
+                    if ((uint32_t)c >= chunks) continue;
                     cnt += (uint32_t)__popcll(gballot(searching && have && kv[c] && kk[c] >= pivot));
                 }
                 if (searching) {
@@ -427,7 +427,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             uint32_t n = 0;
 #pragma unroll
             for (int c = 0; c < KMAX; ++c) {
-                if ((uint32_t)c >= chunks) break;
+                if ((uint32_t)c >= chunks) continue;
                 const bool pred = ok && kv[c] && kk[c] >= tau;
                 const uint64_t gb = gballot(pred);
                 if (pred) { const uint32_t sidx = n + gprefix(gb); L.sKey[sidx] = kk[c]; L.sIdx[sidx] = (uint32_t)c * G + gl; }
@@ -435,7 +435,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             }
             nsd_wave_sync();
             if (ok) { keys = L.sKey; compacted = true; }
-        } else         if (__ballot(want && C > fcap) != 0) {
+        } else if (__ballot(want && C > fcap) != 0) {
             bool searching = want && C > fcap;
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
             bool ok = false;
