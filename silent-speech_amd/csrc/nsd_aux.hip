@@ -162,80 +162,79 @@ extern "C" int nsd_state_init(const NsdTables *t, const NsdBeamState *st, int32_
 // ---------------------------------------------------------------------
 // back-trace
 // ---------------------------------------------------------------------
-// Walks the back-pointers of hypothesis `r0` of utterance u from its last
-// executed step to step 0 and writes BOS + tokens in forward order.
-__device__ int nsd_walk(const uint8_t *backptr, const uint8_t *token, size_t NB, int nsteps,
-                        size_t ubase, int r0, uint8_t *dst /* [T+1] */)
+// One wave per utterance.  The utterance's back-pointers and tokens of all executed steps (nsteps * B bytes
+// each) are first copied into LDS with independent loads, so that following a chain costs LDS latency per
+// step instead of a dependent global load; lane r then walks hypothesis r from its last step to step 0 and
+// writes BOS + tokens in forward order.  `all` = every hypothesis of the beam (token histories for the next
+// model call), otherwise only rank 0 (the result).
+__global__ void __launch_bounds__(64)
+nsd_walk_kernel(NsdBeamState st, const uint8_t *backptr, const uint8_t *token, int T, int N, int B, int all,
+                uint8_t *out_ids, int32_t *out_len, double *out_score)
 {
-    // first pass: count tokens
-    int r = r0, n = 0;
-    for (int t = nsteps - 1; t >= 0; --t) {
-        const size_t o = (size_t)t * NB + ubase + r;
-        if (token[o] != NSD_TOKEN_CARRY) ++n;
-        r = backptr[o];
-    }
-    dst[0] = NSD_BOS;
-    r = r0;
-    int k = n;
-    for (int t = nsteps - 1; t >= 0; --t) {
-        const size_t o = (size_t)t * NB + ubase + r;
-        const uint8_t tk = token[o];
-        if (tk != NSD_TOKEN_CARRY) dst[k--] = tk;
-        r = backptr[o];
-    }
-    return n + 1;
-}
-
-__global__ void nsd_backtrace_kernel(NsdBeamState st, const uint8_t *backptr, const uint8_t *token,
-                                     int T, int N, int B, uint8_t *out_ids, int32_t *out_len, double *out_score)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= N) return;
+    extern __shared__ unsigned char walk_lds[];
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x;
     const uint32_t um = st.utt[u];
+    const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
     int nsteps = (int)(um >> NSD_U_STEPS_SHIFT);
     if (nsteps > T) nsteps = T;
-    out_len[u] = nsd_walk(backptr, token, (size_t)N * B, nsteps, (size_t)u * B, 0, out_ids + (size_t)u * (T + 1));
-    if (out_score) out_score[u] = st.score[(size_t)u * B];
+    uint8_t *bp = walk_lds, *tk = walk_lds + (size_t)T * B;
+    const size_t NB = (size_t)N * B, ubase = (size_t)u * B;
+    for (int i = lane; i < nsteps * B; i += 64) {
+        const size_t o = (size_t)(i / B) * NB + ubase + (size_t)(i % B);
+        bp[i] = backptr[o];
+        tk[i] = token[o];
+    }
+    __syncthreads();
+    const int rows = all ? B : 1;
+    if (lane < rows) {
+        const size_t g = all ? ubase + lane : (size_t)u;
+        int len = 0;
+        if (lane < nbeams) {
+            int r = lane, n = 0;
+            for (int t = nsteps - 1; t >= 0; --t) {
+                if (tk[t * B + r] != NSD_TOKEN_CARRY) ++n;
+                r = bp[t * B + r];
+            }
+            uint8_t *dst = out_ids + g * (size_t)(T + 1);
+            dst[0] = NSD_BOS;
+            r = lane;
+            int k = n;
+            for (int t = nsteps - 1; t >= 0; --t) {
+                const uint8_t c = tk[t * B + r];
+                if (c != NSD_TOKEN_CARRY) dst[k--] = c;
+                r = bp[t * B + r];
+            }
+            len = n + 1;
+        }
+        out_len[g] = len;
+        if (!all && out_score) out_score[u] = st.score[ubase];
+    }
+}
+
+static int nsd_walk_launch(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token, int32_t T, int32_t N,
+                           int32_t B, int all, uint8_t *out_ids, int32_t *out_len, double *out_score, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || T < 0 || T > NSD_MAX_STEPS) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!st || !backptr || !token || !out_ids || !out_len) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_walk_kernel, dim3((unsigned)N), dim3(64), (size_t)2 * (T > 0 ? T : 1) * B, (hipStream_t)stream,
+                       *st, backptr, token, T, N, B, all, out_ids, out_len, out_score);
+    return (int)hipGetLastError();
 }
 
 extern "C" int nsd_backtrace(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token,
                              int32_t T, int32_t N, int32_t B,
                              uint8_t *out_ids, int32_t *out_len, double *out_score, void *stream)
 {
-    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
-    if (N < 0 || T < 0 || T > NSD_MAX_STEPS) return NSD_E_SIZE;
-    if (N == 0) return NSD_OK;
-    if (!st || !backptr || !token || !out_ids || !out_len) return NSD_E_NULL;
-    hipLaunchKernelGGL(nsd_backtrace_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                       *st, backptr, token, T, N, B, out_ids, out_len, out_score);
-    return (int)hipGetLastError();
-}
-
-__global__ void nsd_gather_ids_kernel(NsdBeamState st, const uint8_t *backptr, const uint8_t *token,
-                                      int T, int N, int B, uint8_t *out_ids, int32_t *out_len)
-{
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)N * B) return;
-    const int u = (int)(g / B), r = (int)(g % B);
-    const uint32_t um = st.utt[u];
-    const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
-    int nsteps = (int)(um >> NSD_U_STEPS_SHIFT);
-    if (nsteps > T) nsteps = T;
-    if (r >= nbeams) { out_len[g] = 0; return; }
-    out_len[g] = nsd_walk(backptr, token, (size_t)N * B, nsteps, (size_t)u * B, r, out_ids + (size_t)g * (T + 1));
+    return nsd_walk_launch(st, backptr, token, T, N, B, 0, out_ids, out_len, out_score, stream);
 }
 
 extern "C" int nsd_gather_ids(const NsdBeamState *st, const uint8_t *backptr, const uint8_t *token,
                               int32_t T, int32_t N, int32_t B, uint8_t *out_ids, int32_t *out_len, void *stream)
 {
-    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
-    if (N < 0 || T < 0 || T > NSD_MAX_STEPS) return NSD_E_SIZE;
-    if (N == 0) return NSD_OK;
-    if (!st || !backptr || !token || !out_ids || !out_len) return NSD_E_NULL;
-    const long long tot = (long long)N * B;
-    hipLaunchKernelGGL(nsd_gather_ids_kernel, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       *st, backptr, token, T, N, B, out_ids, out_len);
-    return (int)hipGetLastError();
+    return nsd_walk_launch(st, backptr, token, T, N, B, 1, out_ids, out_len, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------
