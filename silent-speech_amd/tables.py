@@ -131,9 +131,10 @@ def pack_key(s: str) -> Optional[int]:
     return k
 
 
-def _capacity(n: int) -> int:
+def _capacity(n: int, spare: int = 2) -> int:
+    """Power-of-two table size with at least `spare` slots per key."""
     cap = 16
-    while cap < 2 * n:
+    while cap < spare * n:
         cap *= 2
     return cap
 
@@ -285,7 +286,9 @@ def compile_ngram(lm, floor_vsz: Optional[bool] = None) -> NgramTables:
         sl = _place(gkeys, grams.shape[0])
         grams["key"][sl] = gkeys
         grams["logp"][sl] = gvals
-    ctxs = np.zeros(_capacity(len(ckeys)), dtype=CTX_DTYPE)
+    # the decoder probes this table for every unseen transition, mostly with keys it does not hold: at a
+    # load of at most 1/4 three of four such probes end at the first (empty) slot
+    ctxs = np.zeros(_capacity(len(ckeys), 4), dtype=CTX_DTYPE)
     ctxs["key"] = KEY_EMPTY
     if len(ckeys):
         sl = _place(ckeys, ctxs.shape[0])
