@@ -92,6 +92,19 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
             t->n_gram_recs = lm->n_gram_recs;
             t->init_ctx = lm->init_ctx;
         }
+        if (order == 1) {
+            // a unigram model scores the '^' marker itself: log-prob of the n-gram "^", else the empty
+            // context's back-off, else the unseen value
+            t->lm_start = lm->unseen;
+            for (uint64_t h = nsd_mix64(0) & (lm->ctx_cap - 1);; h = (h + 1) & (lm->ctx_cap - 1)) {
+                if (lm->ctxs[h].key == 0) { t->lm_start = lm->ctxs[h].backoff; break; }
+                if (lm->ctxs[h].key == NSD_KEY_EMPTY) break;
+            }
+            for (uint64_t h = nsd_mix64(NSD_SYM_HAT) & (lm->gram_cap - 1);; h = (h + 1) & (lm->gram_cap - 1)) {
+                if (lm->grams[h].key == NSD_SYM_HAT) { t->lm_start = lm->grams[h].logp; break; }
+                if (lm->grams[h].key == NSD_KEY_EMPTY) break;
+            }
+        }
         t->gram_mask = lm->gram_cap - 1;
         t->ctx_mask = lm->ctx_cap - 1;
         t->unseen = lm->unseen;
@@ -127,15 +140,15 @@ extern "C" int nsd_tables_order(const NsdTables *t) { return t ? t->order : NSD_
 // ---------------------------------------------------------------------
 // state init
 // ---------------------------------------------------------------------
-__global__ void nsd_state_init_kernel(NsdBeamState st, int N, int B, uint64_t ctx0, uint32_t id0)
+__global__ void nsd_state_init_kernel(NsdBeamState st, int N, int B, uint64_t ctx0, uint32_t id0, double lm0)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u == 0 && st.done_count) *st.done_count = 0;
     if (u >= N) return;
     const size_t i = (size_t)u * B;
     st.score[i] = 0.0;
-    st.lmsum[i] = 0.0;
-    st.lmsum_e[i] = 0.0;
+    st.lmsum[i] = lm0;
+    st.lmsum_e[i] = lm0;
     st.ctx[i] = ctx0;
     st.hist[i] = NSD_HIST0;
     st.ctx_id[i] = id0;
@@ -155,7 +168,7 @@ extern "C" int nsd_state_init(const NsdTables *t, const NsdBeamState *st, int32_
     // context of the empty surface: '^' cut to the last order-1 symbols
     const uint64_t ctx0 = t->order >= 2 ? (uint64_t)NSD_SYM_HAT : 0ull;
     hipLaunchKernelGGL(nsd_state_init_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *st, N, B,
-                       ctx0, t->init_ctx);
+                       ctx0, t->init_ctx, t->lm_start);
     return (int)hipGetLastError();
 }
 

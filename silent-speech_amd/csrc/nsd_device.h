@@ -19,6 +19,7 @@ struct NsdTables {
     uint32_t     pad;
     double       unseen;
     uint64_t     ctx_sym_mask;   // keeps the last order-1 symbols of a packed context
+    double       lm_start;       // LM sum of the empty surface: the '^' window, which exists for order 1 only
 };
 
 #define NSD_SYM_HAT    38u

@@ -90,7 +90,7 @@ def _run_case_batched(case, dev, with_masks=True):
     tables = DeviceTables.from_words(words, lm)
     dec = NSDecoder(tables, case["beam"], case["max_new_tokens"], variant=case["variant"], lm_weight=case["beta"],
                     oov_penalty=case["gamma"], word_bonus=case["kappa"], length_penalty_alpha=case["alpha"],
-                    min_len_for_eos=case["min_len_for_eos"])
+                    min_len_for_eos=case["min_len_for_eos"], lanes_per_utt=case.get("lanes", 0))
     ws = dec.workspace(len(targets), with_masks=with_masks)
     tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
     err = None
@@ -153,7 +153,7 @@ def test_golden_cases_batched_against_c_checker(golden, dev):
 @pytest.mark.parametrize("variant,beam,order,beta,margin", [
     ("U", 16, 5, 0.05, 60.0), ("I", 16, 5, 0.05, 60.0), ("E", 16, 5, 0.05, 60.0),
     ("U", 32, 5, 0.05, 8.0), ("I", 8, 3, 0.3, 6.0), ("E", 32, 5, 0.1, 10.0), ("U", 2, 2, 0.2, 5.0),
-    ("I", 64, 5, 0.05, 5.0),
+    ("I", 64, 5, 0.05, 5.0), ("U", 8, 1, 0.3, 6.0), ("E", 16, 1, 0.05, 20.0), ("I", 5, 7, 1.0, 2.0),
 ])
 def test_batch_512_against_c_checker(dev, variant, beam, order, beta, margin):
     case = dict(variant=variant, beam=beam, lm_order=order, beta=beta, margin=margin, gamma=1.0, kappa=0.35,
