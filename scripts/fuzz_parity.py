@@ -6,6 +6,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import torch
+from oracle import synth
 from tests.test_gpu_parity import _compare_with_trace, _run_case_batched
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -22,7 +23,15 @@ for k in range(n_cases):
                 max_new_tokens=rng.choice([1, 7, 24, 40]), n_words=rng.choice([3, 40, 200, 3000]), lex_seed=rng.randrange(100),
                 max_len=rng.choice([3, 8]), n_corpus=rng.choice([0, 50, 2000]), corpus_seed=rng.randrange(100),
                 n_utts=rng.choice([1, 7, 64, 200]), target_seed=rng.randrange(100), base_seed=rng.randrange(1 << 30),
-                min_words=1, max_words=rng.choice([1, 4]), lanes=rng.choice([0, gmin, 64]), name=f"fuzz{k}")
+                min_words=1, max_words=rng.choice([1, 4]), lanes=rng.choice([0, gmin, 64]), name=f"fuzz{k}",
+                allow_eos_anytime=rng.random() < 0.8)
+    if rng.random() < 0.3:                          # digits in the lexicon
+        case["alphabet"] = synth.BASE_CHARS[:36]
+    if rng.random() < 0.3:                          # words the decoder cannot spell, phrases with a space edge
+        case["extra_words"] = rng.sample(["don't", "it's", "zq'x", "new york", "a b", "ice cream cone", "x-ray"], 3)
+    if rng.random() < 0.15:
+        case["max_new_tokens"] = rng.choice([64, 128])
+        case["n_utts"] = min(case["n_utts"], 64)
     ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)
     if err is not None:
         assert (ref["lens"] == -1).any(), (case, err)

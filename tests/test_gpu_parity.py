@@ -90,7 +90,8 @@ def _run_case_batched(case, dev, with_masks=True):
     tables = DeviceTables.from_words(words, lm)
     dec = NSDecoder(tables, case["beam"], case["max_new_tokens"], variant=case["variant"], lm_weight=case["beta"],
                     oov_penalty=case["gamma"], word_bonus=case["kappa"], length_penalty_alpha=case["alpha"],
-                    min_len_for_eos=case["min_len_for_eos"], lanes_per_utt=case.get("lanes", 0))
+                    min_len_for_eos=case["min_len_for_eos"], lanes_per_utt=case.get("lanes", 0),
+                    allow_eos_anytime=case.get("allow_eos_anytime", True))
     ws = dec.workspace(len(targets), with_masks=with_masks)
     tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
     err = None
@@ -104,6 +105,7 @@ def _run_case_batched(case, dev, with_masks=True):
     ref = cm.decode_synth(variant=case["variant"], beam=case["beam"], max_new_tokens=case["max_new_tokens"],
                           beta=case["beta"], gamma=case["gamma"], kappa=case["kappa"], alpha=case["alpha"],
                           min_len_for_eos=case["min_len_for_eos"], margin=case["margin"],
+                          allow_eos_anytime=case.get("allow_eos_anytime", True),
                           base_seed=case["base_seed"], targets=tg, target_lens=tl, trace=True)
     return ws, ids, lens, scores, ref, err
 
