@@ -309,13 +309,25 @@ def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, l
     ws = dec.workspace(1)
     dec.init(ws)
     hyps: List[List[int]] = [[BOS_ID]]
+    # torch.topk(k=beam) of the reference's fall-back raises when beam exceeds the vocabulary (copies I and E,
+    # inference_emg_llm.py:281): that happens right after step_fn was called for the first hypothesis without a
+    # lexicon-consistent option, so the remaining hypotheses of the step are never evaluated
+    raises_on_fallback = B > VOCAB and variant != "U"
     for t in range(dec.T):
         rows = torch.zeros(B, VOCAB, dtype=torch.float32)
         dev_rows = []
+        if raises_on_fallback:
+            meta_h = ws.meta[:len(hyps)].tolist()
+            node_h = ws.node[:len(hyps)].tolist()
         for r, ids in enumerate(hyps):
             if ids[-1] == EOS_ID:
                 continue
             out = step_fn(list(ids))
+            if raises_on_fallback:
+                dead = (meta_h[r] & _lib.F_DEAD) or (node_h[r] & 0xFFFFFFFF) == 0xFFFFFFFF
+                mask = 0 if dead else int(tables.nodes["mask"][node_h[r]])
+                if mask & ((1 << 37) - 1) == 0:
+                    raise RuntimeError("selected index k out of range")
             dev_rows.append((r, out.detach().reshape(-1).to(dtype=torch.float32)))
         logits = rows.to(dec.device)
         for r, v in dev_rows:
