@@ -5,6 +5,7 @@ import random, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+import numpy as np
 import torch
 from oracle import synth
 from oracle import ns_oracle as O
@@ -24,6 +25,9 @@ for k in range(n_cases):
                 target_seed=rng.randrange(100), base_seed=rng.randrange(1 << 30), min_words=1, max_words=3)
     if rng.random() < 0.3:
         case["extra_words"] = rng.sample(["don't", "it's", "new york", "a b", "x-ray"], 2)
+    quant = rng.choice([0, 0, 1, 2])
+    if quant:
+        case["beta"] = rng.choice([0.0, case["beta"]])
     words = case_words(case)
     corpus = case_corpus(case, words)
     trie = O.build_trie(words)
@@ -38,7 +42,10 @@ for k in range(n_cases):
         def make(which):
             def step_fn(ids):
                 calls[which].append(list(ids))
-                return torch.from_numpy(synth.logits_row(useed, ids, tgt, case["margin"])).unsqueeze(0)
+                row = synth.logits_row(useed, ids, tgt, case["margin"])
+                if quant:                                   # coarse logits: many exactly equal scores
+                    row = (np.round(row * quant) / quant).astype(np.float32)
+                return torch.from_numpy(row).unsqueeze(0)
             return step_fn
         out = []
         for which, fn in enumerate((lambda sf: O.constrained_beam_decode(sf, O.TextTransformLike, case["beam"], case["max_new_tokens"], trie, lm,
