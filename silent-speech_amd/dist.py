@@ -20,6 +20,24 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_total, lo + per)
 
 
+_KEPT: dict = {}
+
+
+def _kept_rows(n_total: int, world: int, per: int, device) -> torch.Tensor:
+    """Rows of the padded gather that hold utterances (the last shards may be short or empty); cached."""
+    key = (n_total, world, str(device))
+    idx = _KEPT.get(key)
+    if idx is None:
+        parts = []
+        for r in range(world):
+            lo, hi = shard_range(n_total, r, world)
+            parts.append(torch.arange(r * per, r * per + (hi - lo), dtype=torch.long))
+        idx = torch.cat(parts).to(device)
+        _KEPT.clear()
+        _KEPT[key] = idx
+    return idx
+
+
 def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int = 0
                    ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """Collect every rank's (ids u8 [n_r, T+1], lens i32 [n_r]) on `dst`, in utterance order.
@@ -42,12 +60,10 @@ def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int
     dist.all_gather_into_tensor(out, pad)
     if rank != dst:
         return None
-    keep: List[int] = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        keep.extend(range(r * per, r * per + (hi - lo)))
-    idx = torch.tensor(keep, dtype=torch.long, device=ids.device)
-    rows = out.index_select(0, idx)
+    if per * world == n_total:
+        rows = out                                  # equal shards: the gathered rows are already in order
+    else:
+        rows = out.index_select(0, _kept_rows(n_total, world, per, ids.device))
     len_bytes = torch.empty(rows.shape[0], 4, dtype=torch.uint8, device=ids.device)   # fresh, aligned storage
     len_bytes.copy_(rows[:, width:])
     all_len = len_bytes.view(torch.int32).reshape(-1)
