@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure throughput run)")
     args = ap.parse_args()
 
+    if os.environ.get("NSD_BENCH_WATCHDOG"):        # diagnostic: periodic stack dumps of a run that seems stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NSD_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,7 +308,8 @@ def main():
         out = one_decode(True, k)
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # gloo reduces host tensors
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -316,8 +320,8 @@ def main():
     from silent_speech_amd.decoder import ids_to_text
     from silent_speech_amd import TextTransform
     texts = [ids_to_text(TextTransform, ids_np[u, :lens_np[u]].tolist()) for u in range(args.utts)]
-    chars = torch.tensor([sum(len(s) for s in texts)], dtype=torch.float64, device=dev)
-    exact = torch.tensor([sum(int(a == b) for a, b in zip(texts, targets))], dtype=torch.float64, device=dev)
+    chars = torch.tensor([sum(len(s) for s in texts)], dtype=torch.float64, device=rdev)
+    exact = torch.tensor([sum(int(a == b) for a, b in zip(texts, targets))], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(chars)
         dist.all_reduce(exact)

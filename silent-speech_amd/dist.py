@@ -56,8 +56,14 @@ def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int
     pad = torch.zeros(per, width + 4, dtype=torch.uint8, device=ids.device)
     pad[:n, :width] = ids
     pad[:n, width:] = lens.to(torch.int32).contiguous().view(torch.uint8).reshape(n, 4)
-    out = torch.empty(world * per, width + 4, dtype=torch.uint8, device=ids.device)
-    dist.all_gather_into_tensor(out, pad)
+    if ids.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of the multi-rank path without RCCL (several ranks on one GPU): gloo exchanges host memory
+        host = torch.empty(world * per, width + 4, dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, pad.cpu())
+        out = host.to(ids.device)
+    else:
+        out = torch.empty(world * per, width + 4, dtype=torch.uint8, device=ids.device)
+        dist.all_gather_into_tensor(out, pad)
     if rank != dst:
         return None
     if per * world == n_total:
