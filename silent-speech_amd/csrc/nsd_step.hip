@@ -1,24 +1,27 @@
 // nsd_step: one NS decode step for N utterances x B beams (gfx950).
 //
-// Work split: G lanes per utterance (G = 16, 32 or 64, the smallest >= B), so a
-// 64-lane wave carries 64/G utterances; every ballot, prefix sum and LDS region
-// is local to such a lane group and no block-level barrier is used.
-//   phase 1  lane b of a group loads hypothesis b's state, then (second
-//            dependent hop) its trie node record and its n-gram context
-//            record, into the group's LDS region
+// Work split: G lanes per utterance (G = 16, 32 or 64, at least B; chosen by the
+// launcher from the batch size), so a 64-lane wave carries 64/G utterances; every
+// ballot, prefix sum and LDS region is local to such a lane group and no
+// block-level barrier is used.
+//   phase 1  lane b of a group loads hypothesis b's state (requested together
+//            with the utterance word), then (second dependent hop) its trie node
+//            record and its n-gram context record, into the group's LDS region
 //   passes   G/8 live logits rows per pass and utterance, 8 lanes per row
 //            (5 consecutive logits per lane): deterministic log-softmax,
 //            lexicon mask applied, the allowed (hypothesis, token) pairs are
-//            appended to the group's LDS candidate buffer and scored at once,
-//            one lane per new candidate: one context-automaton record load
-//            (third hop), beta/gamma/kappa fusion, fp64 score and pruning key.
-//            The buffer is bounded: when a pass might overflow it, the buffer
-//            is first pruned to its top-B (which cannot change the final top-B)
-//   select   top-B of the buffer: a ballot quickselect finds a threshold that
-//            leaves at most 2G candidates, then every lane counts over
-//            broadcast LDS reads how many survivors beat its own; that count
-//            is the rank (exact score ties take a slower pass that also
-//            compares the emission order)
+//            appended to the group's LDS candidate buffer.
+//            The buffer is bounded: when a pass might overflow it, what it holds
+//            is scored and pruned to its top-B first (which cannot change the
+//            final top-B)
+//   score    one lane per candidate: one context-automaton record load (third
+//            hop; a hash probe for an unseen transition), beta/gamma/kappa
+//            fusion, fp64 score and pruning key
+//   select   top-B of the buffer: up to 2G candidates are ranked directly, two
+//            per lane, each lane counting over broadcast LDS reads how many keys
+//            beat its own; beyond that a ballot quickselect first finds a
+//            threshold that leaves at most 2G candidates (exact score ties take
+//            a slower pass that also compares the emission order)
 //   write    lane r writes surviving hypothesis r: new score, n-gram state,
 //            trie child, flags, history hash, back-pointer and token
 //
