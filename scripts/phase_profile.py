@@ -49,8 +49,7 @@ for t in range(40):
         s = stamps.cpu().numpy()
         act = s[:, 5] > 0
         d = np.diff(s[act, :6], axis=1).astype(np.float64)
-        fine = {"pass0: lds+prefetch": s[act, 6] - s[act, 1], "pass0: softmax": s[act, 7] - s[act, 6],
-                "pass0: emit": s[act, 8] - s[act, 7], "final select: threshold": s[act, 9] - s[act, 3],
+        fine = {"pass0: until its logits are there": s[act, 6] - s[act, 1], "final select: threshold": s[act, 9] - s[act, 3],
                 "final select: rank": s[act, 4] - s[act, 9]}
         tot = (s[act, 5] - s[act, 0]).astype(np.float64)
         Cc = s[act, 10].astype(np.int64)

@@ -664,7 +664,6 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         if (pass + 1 < npass_max) fetch_row(pass + 1);
         if (pass == 0) NSD_STAMP(6);
         nsd_row_log_softmax5(x);
-        if (pass == 0) NSD_STAMP(7);
 
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -677,7 +676,6 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             emit(is_char || is_eos, x[k], pack_info(v, kind, w, (uint32_t)r));
         }
 
-        if (pass == 0) NSD_STAMP(8);
         // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
         if (__ballot(fb) != 0) {
             float *rb = L.rowbuf + (gl >> 3) * NSD_V;
