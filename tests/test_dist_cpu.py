@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from silent_speech_amd.dist import gather_results, shard_range
+from silent_speech_amd.dist import gather_results, last_gathered, unpack_gathered, shard_range
 
 
 def test_shard_range_covers_everything():
@@ -36,8 +36,13 @@ def _worker(rank, world, port, n_total, q):
     for i, u in enumerate(range(lo, hi)):
         ids[i] = torch.tensor([37, u % 36, (u // 36) % 36, 38, 0], dtype=torch.uint8)
         lens[i] = 4
+    # first the deferred form (exchange only, unpacked from the kept receive buffer), then the direct one
+    assert gather_results(ids, lens, n_total, dst=0, unpack=False) is None
+    per = (n_total + world - 1) // world
+    late = unpack_gathered(last_gathered(per, 5, world, ids.device), n_total, 5) if rank == 0 else None
     out = gather_results(ids, lens, n_total, dst=0)
     if rank == 0:
+        assert torch.equal(late[0], out[0]) and torch.equal(late[1], out[1])
         q.put((out[0].numpy(), out[1].numpy()))
     else:
         assert out is None
