@@ -299,8 +299,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         C += (uint32_t)__popcll(gb);
     };
 
-    // score candidates [from, C) of this group, one lane each
-    auto score_new = [&](uint32_t from) {
+    // score candidates [from, C) of this group, one lane each.  With `keep` (group-uniform; needs
+    // 2 C <= CAP) the n-gram transition of a character or space candidate is left in the unused top of
+    // the buffer (entry CAP-1-i for candidate i), where the write phase finds it for the survivors.
+    auto score_new = [&](uint32_t from, bool keep) {
         const uint32_t rounds = wave_max(act && C > from ? (C - from + G - 1) / G : 0u);
         for (uint32_t rd = 0; rd < rounds; ++rd) {
             const uint32_t i = from + rd * G + gl;
@@ -324,12 +326,31 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
                 const int ms = 1 + glen - pend;
                 const bool whole = (L.bMask[p] >> 37) & 1;
+                const bool is_eos = kind == K_EOS;
+                const bool is_sp = !is_eos && tok == NSD_SPACE;
                 double add = lp;
-                if (kind == K_EOS || tok == NSD_SPACE) {
+                // One transition serves both kinds: a character extends the effective context; a space
+                // (only offered without a pending one, when effective and stripped state coincide) is
+                // scored on the stripped surface and its transition is only kept for the write phase.
+                NsdLmStep s;
+                s.full_new = false; s.term = 0.0;
+                double lgn = 0.0;
+                if (use_lm && !is_eos && (keep || !is_sp)) {
+                    const uint64_t ctx = L.bCtx[p];
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                    s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p], L.bBo[p], tok + 1u);
+                    lgn = L.bGe[p];
+                    if (s.has_int) lgn = lgn + s.lint;
+                    if (keep) {
+                        L.cKey[CAP - 1u - i] = lgn;
+                        L.cInfo[CAP - 1u - i] = s.full_new ? s.next_id : NSD_CTX_NONE;
+                    }
+                }
+                if (is_eos || is_sp) {
                     // both score the stripped surface: logp(surf + " ") == logp(surf)
                     double lg = L.bG[p];
                     if (ms + 1 >= order) lg = lg + L.bTermS[p];
-                    if (kind == K_EOS) {                   // variant E boundary EOS (eval_ar.py:290-296)
+                    if (is_eos) {                          // variant E boundary EOS (eval_ar.py:290-296)
                         add -= P.eos_len_nudge * (double)glen;
                         if (use_lm && glen > 0) add += P.beta * lg;
                     } else {
@@ -338,12 +359,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                         if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
                     }
                 } else if (use_lm) {
-                    const uint64_t ctx = L.bCtx[p];
-                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p],
-                                                       L.bBo[p], tok + 1u);
-                    double lg = L.bGe[p];
-                    if (s.has_int) lg = lg + s.lint;
+                    double lg = lgn;
                     if (s.full_new) lg = lg + s.term;
                     add += P.beta * lg;
                 }
@@ -488,6 +504,31 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             }
             nsd_wave_sync();
             if (ok) { keys = L.sKey; compacted = true; }
+        }
+        else if (__ballot(want && C > (uint32_t)G) != 0) {
+            // G < C <= 2G: a bound from cell maxima.  The lanes form `cells` >= nsel cells; the nsel-th best
+            // key is at least the smallest of the cells' best keys, so everything below that value is out.
+            // Usually fewer than G candidates remain, and one per lane is ranked instead of two.
+            const bool in = want && C > (uint32_t)G;
+            const uint32_t i1 = (uint32_t)gl + G;
+            const bool h1 = in && i1 < C;
+            const double a0 = in ? L.cKey[gl] : 0.0, a1 = h1 ? L.cKey[i1] : 0.0;
+            int cells = 1;
+            while (cells < nsel) cells <<= 1;
+            const int cell = G / cells;            // lanes per cell (nsel <= B <= G)
+            double m = h1 ? fmax(a0, a1) : a0;
+            for (int d = 1; d < G; d <<= 1) {
+                const double o = __shfl_xor(m, d);
+                m = d < cell ? fmax(m, o) : fmin(m, o);
+            }
+            const bool p0 = in && a0 >= m, p1 = h1 && a1 >= m;
+            const uint64_t g0 = gballot(p0), g1 = gballot(p1);
+            const uint32_t n0 = (uint32_t)__popcll(g0), n = n0 + (uint32_t)__popcll(g1);
+            const bool ok = in && n <= (uint32_t)G && n >= (uint32_t)nsel;
+            if (ok && p0) { const uint32_t sidx = gprefix(g0); L.sKey[sidx] = a0; L.sIdx[sidx] = (uint32_t)gl; }
+            if (ok && p1) { const uint32_t sidx = n0 + gprefix(g1); L.sKey[sidx] = a1; L.sIdx[sidx] = i1; }
+            nsd_wave_sync();
+            if (ok) { keys = L.sKey; compacted = true; F = n; }
         }
         NSD_STAMP(9);
         // ---- rank among the F <= 2G survivors: two per lane ----
@@ -648,7 +689,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             const bool over = act && C + add > CAP;
             if (__ballot(over) != 0) {
                 NSD_TIC();
-                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored); nsd_wave_sync(); }
+                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); }
                 NSD_TOC(dbg_t_score);
                 scored = C;
                 NSD_TIC();
@@ -701,7 +742,9 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     }
     NSD_STAMP(2);
     nsd_wave_sync();
-    score_new(scored);
+    // nothing scored or pruned so far and the upper half of the buffer free: transitions can be kept
+    const bool kept = act && scored == 0 && 2u * C <= CAP;
+    score_new(scored, kept);
     nsd_wave_sync();
     NSD_STAMP(3);
 
@@ -751,7 +794,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 // The space joins the LM sum only once a character follows it: keep the stripped state
                 // and prepare the effective one (context + space).  A hypothesis with a pending space
                 // sits at the trie root, which never allows a space, so pend == 0 here.
-                if (use_lm) {
+                if (use_lm && kept) {
+                    Ge = L.cKey[CAP - 1u - mysel];
+                    ctxe_id = L.cInfo[CAP - 1u - mysel];
+                } else if (use_lm) {
                     const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctx, ctx_id, L.bSym[p], L.bLmBase[p],
                                                        L.bBo[p], NSD_SPACE + 1u);
                     Ge = s.has_int ? G0 + s.lint : G0;
@@ -760,7 +806,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 flags |= NSD_F_PENDING_SPACE;
                 node = 0;
             } else {
-                if (use_lm) {
+                if (use_lm && kept) {
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                    G0 = Ge = L.cKey[CAP - 1u - mysel];
+                    ctx = nsd_ctx_shift(a.tab, ctxe, tok + 1u);
+                    ctx_id = ctxe_id = L.cInfo[CAP - 1u - mysel];
+                } else if (use_lm) {
                     const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
                     const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, ctxe_id, L.bSym[p], L.bLmBase[p],
                                                        L.bBo[p], tok + 1u);
