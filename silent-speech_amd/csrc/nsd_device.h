@@ -121,6 +121,31 @@ NSD_D float nsd_dpp_half_mirror(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
 }
 
+// Two exponentials at once with the packed fp32 instructions (v_pk_mul/fma/add_f32 are IEEE per element,
+// so each half has the bits of nsd_det_expf).
+typedef float nsd_f2 __attribute__((ext_vector_type(2)));
+
+NSD_D nsd_f2 nsd_det_expf2(nsd_f2 d)
+{
+    const nsd_f2 t = d * 1.44269504088896341f;
+    const nsd_f2 k = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    nsd_f2 r = __builtin_elementwise_fma(k, (nsd_f2)(-0.693359375f), d);
+    r = __builtin_elementwise_fma(k, (nsd_f2)(2.12194440e-4f), r);
+    const nsd_f2 z = r * r;
+    nsd_f2 y = (nsd_f2)(1.9875691500e-4f);
+    y = __builtin_elementwise_fma(y, r, (nsd_f2)(1.3981999507e-3f));
+    y = __builtin_elementwise_fma(y, r, (nsd_f2)(8.3334519073e-3f));
+    y = __builtin_elementwise_fma(y, r, (nsd_f2)(4.1665795894e-2f));
+    y = __builtin_elementwise_fma(y, r, (nsd_f2)(1.6666665459e-1f));
+    y = __builtin_elementwise_fma(y, r, (nsd_f2)(5.0000001201e-1f));
+    y = __builtin_elementwise_fma(y, z, r);
+    y = y + 1.0f;
+    nsd_f2 o;
+    o.x = d.x >= -80.0f ? __builtin_ldexpf(y.x, (int)k.x) : 0.0f;
+    o.y = d.y >= -80.0f ? __builtin_ldexpf(y.y, (int)k.y) : 0.0f;
+    return o;
+}
+
 NSD_D void nsd_row_log_softmax5(float (&x)[5])
 {
     // After the distance-1 and distance-2 steps the four lanes of a quad hold the same value, so the
@@ -129,19 +154,24 @@ NSD_D void nsd_row_log_softmax5(float (&x)[5])
     m = fmaxf(m, nsd_dpp_xor1(m));
     m = fmaxf(m, nsd_dpp_xor2(m));
     m = fmaxf(m, nsd_dpp_half_mirror(m));
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        x[k] = x[k] - m;
-        float e = nsd_det_expf(x[k]);
-        s = (k == 0) ? e : s + e;
-    }
+    nsd_f2 a = {x[0], x[1]}, b = {x[2], x[3]};
+    a = a - m;
+    b = b - m;
+    const float c = x[4] - m;
+    const nsd_f2 ea = nsd_det_expf2(a), eb = nsd_det_expf2(b);
+    const float ec = nsd_det_expf(c);
+    float s = ea.x;                               // left to right, as a scalar loop would
+    s = s + ea.y;
+    s = s + eb.x;
+    s = s + eb.y;
+    s = s + ec;
     s = s + nsd_dpp_xor1(s);
     s = s + nsd_dpp_xor2(s);
     s = s + nsd_dpp_half_mirror(s);
-    float lse = nsd_det_logf(s);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) x[k] = x[k] - lse;
+    const float lse = nsd_det_logf(s);
+    a = a - lse;
+    b = b - lse;
+    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c - lse;
 }
 
 // ---------------------------------------------------------------------

@@ -147,7 +147,7 @@ static size_t nsd_step_lds_per_utt(int B, int G, int variant, uint32_t *cap_out)
 }
 
 template <int G, int VARIANT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 nsd_step_kernel(StepArgs a, NsdParams P)
 {
     constexpr int UPW = 64 / G;                   // utterances per wave
@@ -382,24 +382,51 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint32_t F = want ? C : 0u;
         const double *keys = L.cKey;
         bool compacted = false, full_scan = false;
-        // ---- threshold: at most fcap survivors (one per lane when the beam allows it) ----
-        // two candidates per lane are ranked directly: a search only pays beyond that
+        // ---- threshold: at most fcap survivors, two per lane ----
         const uint32_t fcap = 2u * (uint32_t)G;
         constexpr int KMAX = 4;                    // keys a lane keeps in registers during the search
-        if (__ballot(want && C > fcap) != 0 && chunks <= (uint32_t)KMAX) {
-            // The search runs on registers: lane gl holds candidates gl, gl + G, ...; a pivot is broadcast
-            // from the lane that owns it and counted with one compare + ballot per held key.
-            bool searching = want && C > fcap;
+        if (__ballot(want && C > (uint32_t)G) != 0 && chunks <= (uint32_t)KMAX) {
+            // Runs on registers: lane gl holds candidates gl, gl + G, ...
+            const bool in = want && C > (uint32_t)G;
             double kk[KMAX];
             bool kv[KMAX];
 #pragma unroll
             for (int c = 0; c < KMAX; ++c) {
                 const uint32_t i = (uint32_t)c * G + gl;
-                kv[c] = searching && i < C;
+                kv[c] = in && i < C;
                 kk[c] = kv[c] ? L.cKey[i] : 0.0;
             }
+            // A bound from cell maxima first.  The lanes form `cells` >= nsel cells (every lane holds a
+            // candidate, as C > G); the nsel-th best key is at least the smallest of the cells' best keys,
+            // so everything below that value is out.  Usually that already leaves fewer than G candidates.
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
-            bool ok = false;
+            bool ok = false, searching = false;
+            {
+                int cells = 1;
+                while (cells < nsel) cells <<= 1;
+                const int cell = G / cells;        // lanes per cell (nsel <= B <= G)
+                double m = kk[0];
+#pragma unroll
+                for (int c = 1; c < KMAX; ++c) m = kv[c] ? fmax(m, kk[c]) : m;
+#pragma unroll
+                for (int d = 1; d < G; d <<= 1) {
+                    const double o = __shfl_xor(m, d);
+                    m = d < cell ? fmax(m, o) : fmin(m, o);
+                }
+                uint32_t n = 0;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    if ((uint32_t)c >= chunks) continue;          // uniform: chunks the buffer does not have
+                    n += (uint32_t)__popcll(gballot(kv[c] && kk[c] >= m));
+                }
+                if (in) {
+                    if (n < (uint32_t)nsel) full_scan = true;                 // only with NaN keys
+                    else if (n <= fcap) { ok = true; tau = m; F = n; }
+                    else { searching = true; lo = m; }
+                }
+            }
+            // Beyond fcap survivors: a pivot is broadcast from the lane that owns it and counted with one
+            // compare + ballot per held key.
             for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
                 NSD_COUNT(dbg_iters);
                 bool have = false;
@@ -505,31 +532,6 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             nsd_wave_sync();
             if (ok) { keys = L.sKey; compacted = true; }
         }
-        else if (__ballot(want && C > (uint32_t)G) != 0) {
-            // G < C <= 2G: a bound from cell maxima.  The lanes form `cells` >= nsel cells; the nsel-th best
-            // key is at least the smallest of the cells' best keys, so everything below that value is out.
-            // Usually fewer than G candidates remain, and one per lane is ranked instead of two.
-            const bool in = want && C > (uint32_t)G;
-            const uint32_t i1 = (uint32_t)gl + G;
-            const bool h1 = in && i1 < C;
-            const double a0 = in ? L.cKey[gl] : 0.0, a1 = h1 ? L.cKey[i1] : 0.0;
-            int cells = 1;
-            while (cells < nsel) cells <<= 1;
-            const int cell = G / cells;            // lanes per cell (nsel <= B <= G)
-            double m = h1 ? fmax(a0, a1) : a0;
-            for (int d = 1; d < G; d <<= 1) {
-                const double o = __shfl_xor(m, d);
-                m = d < cell ? fmax(m, o) : fmin(m, o);
-            }
-            const bool p0 = in && a0 >= m, p1 = h1 && a1 >= m;
-            const uint64_t g0 = gballot(p0), g1 = gballot(p1);
-            const uint32_t n0 = (uint32_t)__popcll(g0), n = n0 + (uint32_t)__popcll(g1);
-            const bool ok = in && n <= (uint32_t)G && n >= (uint32_t)nsel;
-            if (ok && p0) { const uint32_t sidx = gprefix(g0); L.sKey[sidx] = a0; L.sIdx[sidx] = (uint32_t)gl; }
-            if (ok && p1) { const uint32_t sidx = n0 + gprefix(g1); L.sKey[sidx] = a1; L.sIdx[sidx] = i1; }
-            nsd_wave_sync();
-            if (ok) { keys = L.sKey; compacted = true; F = n; }
-        }
         NSD_STAMP(9);
         // ---- rank among the F <= 2G survivors: two per lane ----
         uint32_t claimed = 0;
@@ -555,8 +557,18 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                     }
                     if (Fmax & 1u) r0 += (keys[Fmax - 1] > k0) ? 1u : 0u;
                 } else {
+                    // several utterances per wave: each group reads its own keys, pairs past its F are skipped
+                    const double2 *k2 = reinterpret_cast<const double2 *>(keys);
+                    const uint32_t pairs = Fmax >> 1, mine = run ? F >> 1 : 0u;
 #pragma unroll 4
-                    for (uint32_t q = 0; q < Fmax; ++q) r0 += (q < F && keys[q] > k0) ? 1u : 0u;
+                    for (uint32_t q = 0; q < pairs; ++q) {
+                        if (q < mine) {
+                            const double2 k = k2[q];
+                            r0 += (k.x > k0) ? 1u : 0u;
+                            r0 += (k.y > k0) ? 1u : 0u;
+                        }
+                    }
+                    if (run && (F & 1u)) r0 += (keys[F - 1] > k0) ? 1u : 0u;
                 }
             } else if (UPW == 1) {
                 const double2 *k2 = reinterpret_cast<const double2 *>(keys);
@@ -575,11 +587,22 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                     r1 += (k > k1) ? 1u : 0u;
                 }
             } else {
+                const double2 *k2 = reinterpret_cast<const double2 *>(keys);
+                const uint32_t pairs = Fmax >> 1, mine = run ? F >> 1 : 0u;
 #pragma unroll 2
-                for (uint32_t q = 0; q < Fmax; ++q) {
-                    const double k = keys[q];
-                    r0 += (q < F && k > k0) ? 1u : 0u;
-                    r1 += (q < F && k > k1) ? 1u : 0u;
+                for (uint32_t q = 0; q < pairs; ++q) {
+                    if (q < mine) {
+                        const double2 k = k2[q];
+                        r0 += (k.x > k0) ? 1u : 0u;
+                        r1 += (k.x > k1) ? 1u : 0u;
+                        r0 += (k.y > k0) ? 1u : 0u;
+                        r1 += (k.y > k1) ? 1u : 0u;
+                    }
+                }
+                if (run && (F & 1u)) {
+                    const double k = keys[F - 1];
+                    r0 += (k > k0) ? 1u : 0u;
+                    r1 += (k > k1) ? 1u : 0u;
                 }
             }
             const bool w0 = v0 && r0 < (uint32_t)nsel, w1 = v1 && r1 < (uint32_t)nsel;
