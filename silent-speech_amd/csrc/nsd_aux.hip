@@ -536,38 +536,56 @@ extern "C" int nsd_kv_reorder(const void *src, void *dst, const uint8_t *backptr
 }
 
 // ---------------------------------------------------------------------
-// synthetic logits: one thread per 16-byte quarter-decade of a row (10 threads per row), so that a wave
-// writes 1 KB of consecutive bytes with one dwordx4 store per lane
+// synthetic logits: a wave takes ROWS consecutive rows.  Lane = row for the row's hash (state loads and
+// three 64-bit mixes, once per row), then the wave writes its ROWS * 160 bytes in rounds of one dwordx4 store
+// per lane (1 KB of consecutive bytes per round), fetching the row's hash from the lane that owns it.
+// ROWS = 64 does the least work per row; 16 has the shortest wave and suits launches that do not fill the chip.
 // ---------------------------------------------------------------------
+template <uint32_t ROWS>
 __global__ void __launch_bounds__(256)
 nsd_synth_logits_kernel(NsdBeamState st, uint64_t base_seed, long long utt0, const int8_t *targets,
                         const int32_t *target_len, int stride, float margin, float *logits, uint32_t nrows, uint32_t B)
 {
-    const uint32_t q4 = blockIdx.x * blockDim.x + threadIdx.x;          // index of the float4
-    const uint32_t row = q4 / 10u, c = q4 - row * 10u;
-    if (row >= nrows) return;
-    const uint32_t u = row / B, r = row - u * B;
-    // independent loads first (slots past the beam count hold stale values that are dropped below)
-    const uint32_t um = st.utt[u];
-    const uint32_t meta = st.meta[row];
-    const uint64_t hist = st.hist[row];
-    const int tlen = target_len[u];
-    if ((um & NSD_U_DONE) || r >= (um & NSD_U_NBEAMS_MASK)) return;
-    if (meta & NSD_F_FINISHED) return;
-    const int step = (int)(meta >> 8);
-    const int tgt = step < tlen ? (int)targets[(size_t)u * stride + step] : NSD_EOS;
-    const uint64_t useed = nsd_mix64(base_seed + (uint64_t)(utt0 + u) * 0xD1B54A32D192ED03ull);
-    const uint64_t k = nsd_mix64(hist ^ nsd_mix64(useed + (uint64_t)step * NSD_GOLD));
-    const uint32_t rk = (uint32_t)(k ^ (k >> 32));
-    float x[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t v = c * 4u + q;
-        const uint32_t h = nsd_fmix32(rk + v * 0x9E3779B9u);
-        x[q] = ((float)(h >> 8) * 5.9604644775390625e-08f - 0.5f) * 4.0f;
-        if ((int)v == tgt) x[q] = x[q] + margin;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= nrows) return;
+    const uint32_t row = row0 + lane;
+    uint32_t rk = 0;
+    int tgt = -1;                                            // -1: nothing to write for this row
+    if (lane < ROWS && row < nrows) {
+        const uint32_t u = row / B, r = row - u * B;
+        // independent loads first (slots past the beam count hold stale values that are dropped below)
+        const uint32_t um = st.utt[u];
+        const uint32_t meta = st.meta[row];
+        const uint64_t hist = st.hist[row];
+        const int tlen = target_len[u];
+        if (!(um & NSD_U_DONE) && r < (um & NSD_U_NBEAMS_MASK) && !(meta & NSD_F_FINISHED)) {
+            const int step = (int)(meta >> 8);
+            tgt = step < tlen ? (int)targets[(size_t)u * stride + step] : NSD_EOS;
+            const uint64_t useed = nsd_mix64(base_seed + (uint64_t)(utt0 + u) * 0xD1B54A32D192ED03ull);
+            const uint64_t k = nsd_mix64(hist ^ nsd_mix64(useed + (uint64_t)step * NSD_GOLD));
+            rk = (uint32_t)(k ^ (k >> 32));
+        }
     }
-    reinterpret_cast<float4 *>(logits)[q4] = make_float4(x[0], x[1], x[2], x[3]);
+    float4 *out = reinterpret_cast<float4 *>(logits) + (size_t)row0 * 10u;
+    constexpr uint32_t NF4 = ROWS * 10u;                     // float4s of the wave's block
+#pragma unroll 2
+    for (uint32_t i = 0; i < (NF4 + 63u) / 64u; ++i) {
+        const uint32_t f = i * 64u + lane;
+        const uint32_t rl = (f / 10u) & 63u, c = f - (f / 10u) * 10u;
+        const uint32_t rk_r = (uint32_t)__shfl((int)rk, (int)rl);
+        const int tgt_r = __shfl(tgt, (int)rl);
+        if (f >= NF4 || tgt_r < 0) continue;
+        float x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t v = c * 4u + q;
+            const uint32_t h = nsd_fmix32(rk_r + v * 0x9E3779B9u);
+            x[q] = ((float)(h >> 8) * 5.9604644775390625e-08f - 0.5f) * 4.0f;
+            if ((int)v == tgt_r) x[q] = x[q] + margin;
+        }
+        out[f] = make_float4(x[0], x[1], x[2], x[3]);
+    }
 }
 
 extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int64_t utt0,
@@ -578,11 +596,16 @@ extern "C" int nsd_synth_logits(const NsdBeamState *st, uint64_t base_seed, int6
     if (N < 0 || stride < 0) return NSD_E_SIZE;
     if (N == 0) return NSD_OK;
     if (!st || !targets || !target_len || !logits) return NSD_E_NULL;
-    const long long threads = (long long)N * B * 10;                    // float4s of the logits array
-    if (threads > 0xFFFFFFFFll) return NSD_E_SIZE;
-    hipLaunchKernelGGL(nsd_synth_logits_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, *st, base_seed, (long long)utt0, targets, target_len, stride,
-                       margin, logits, (uint32_t)((long long)N * B), (uint32_t)B);
+    const long long rows = (long long)N * B;
+    if (rows * 10 > 0xFFFFFFFFll) return NSD_E_SIZE;
+    if (rows >= 262144)
+        hipLaunchKernelGGL(nsd_synth_logits_kernel<64>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, *st, base_seed, (long long)utt0, targets, target_len, stride,
+                           margin, logits, (uint32_t)rows, (uint32_t)B);
+    else
+        hipLaunchKernelGGL(nsd_synth_logits_kernel<16>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0,
+                           (hipStream_t)stream, *st, base_seed, (long long)utt0, targets, target_len, stride,
+                           margin, logits, (uint32_t)rows, (uint32_t)B);
     return (int)hipGetLastError();
 }
 
