@@ -16,14 +16,17 @@
 //            final top-B)
 //   score    one lane per candidate: one context-automaton record load (third
 //            hop; a hash probe for an unseen transition), beta/gamma/kappa
-//            fusion, fp64 score and pruning key
-//   select   top-B of the buffer: up to 2G candidates are ranked directly, two
-//            per lane, each lane counting over broadcast LDS reads how many keys
-//            beat its own; beyond that a ballot quickselect first finds a
-//            threshold that leaves at most 2G candidates (exact score ties take
-//            a slower pass that also compares the emission order)
-//   write    lane r writes surviving hypothesis r: new score, n-gram state,
-//            trie child, flags, history hash, back-pointer and token
+//            fusion, fp64 score and pruning key; the transition itself is left in
+//            the unused top of the candidate buffer for the write phase
+//   select   top-B of the buffer: up to G candidates are ranked directly, one per
+//            lane, each lane counting over broadcast LDS reads how many keys beat
+//            its own; beyond G a bound from cell maxima first drops what cannot
+//            be in the top-B, the rest is compacted and ranked one or two per
+//            lane; a ballot quickselect only runs if more than 2G remain (exact
+//            score ties take a slower pass that also compares the emission order)
+//   write    lane r writes surviving hypothesis r: new score, n-gram state (from
+//            the kept transition), trie child, flags, history hash, back-pointer
+//            and token
 //
 // Restates the loop body of scripts/ns_utils.py:218-275 (variant U),
 // inference_emg_llm.py:239-297 (I) and eval_ar.py:243-313 (E) of the
