@@ -564,6 +564,48 @@ def test_full_size_batch_properties(variant):
 
 
 @pytest.mark.gpu
+def test_one_gpu_share_of_the_million_utterance_batch():
+    """One GPU's share of the 1 000 000-utterance configuration over 8 GPUs (131 072 utterances, beam 16; the
+    launcher then puts two utterances on a wave): slices of the batch decoded on their own (one utterance per
+    wave) give the same ids / lengths / fp64 scores, a second decode gives the same bits, and the first
+    utterances equal the C checker."""
+    from silent_speech_amd import synthetic as S
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    from silent_speech_amd.tables import NgramCounts
+    dev = torch.device("cuda", 0)
+    N, B, T, seed, margin = 131072, 16, 64, 20260403, 60.0
+    words = S.make_lexicon(200, 0)
+    corpus = S.make_sentences(words, 20000, 1)
+    tg, tl = S.pack_targets(S.make_sentences(words, N, 1000, 3, 7))
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    tables = DeviceTables.from_words(words, NgramCounts(5, floor_vsz=False).fit(corpus))
+    dec = NSDecoder(tables, B, T, variant="I", lm_weight=0.05, oov_penalty=1.0)
+
+    def run(lo, hi):
+        ids, lens, sc = dec.decode_synth_native(tgd[lo:hi].contiguous(), tld[lo:hi].contiguous(), base_seed=seed,
+                                                margin=margin, utt0=lo)
+        torch.cuda.synchronize()
+        return ids.cpu().numpy().copy(), lens.cpu().numpy().copy(), sc.cpu().numpy().copy()
+
+    ids, lens, sc = run(0, N)
+    ids2, lens2, sc2 = run(0, N)
+    assert (ids == ids2).all() and (lens == lens2).all() and (sc.view(np.int64) == sc2.view(np.int64)).all()
+    for lo, hi in ((0, 512), (65000, 66000), (N - 300, N)):
+        i3, l3, s3 = run(lo, hi)
+        assert (l3 == lens[lo:hi]).all(), (lo, hi)
+        assert (i3 == ids[lo:hi]).all(), (lo, hi)
+        assert (s3.view(np.int64) == sc[lo:hi].view(np.int64)).all(), (lo, hi)
+    n = 24
+    ref = cbind.Model(words, corpus, 5, False).decode_synth(
+        variant="I", beam=B, max_new_tokens=T, beta=0.05, gamma=1.0, kappa=0.0, margin=margin, base_seed=seed,
+        targets=tg[:n], target_lens=tl[:n], trace=False)
+    assert (ref["lens"] == lens[:n]).all()
+    for u in range(n):
+        assert (ref["ids"][u, :lens[u]] == ids[u, :lens[u]]).all(), u
+        assert float(ref["scores"][u]).hex() == float(sc[u]).hex(), u
+
+
+@pytest.mark.gpu
 def test_step_into_a_second_state_buffer_equals_in_place():
     """nsd_step may write the new hypothesis state into other arrays than it reads (double buffering): the
     result equals stepping in place, including utterances that are already finished (their state is copied)."""
