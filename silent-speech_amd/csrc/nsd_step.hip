@@ -715,9 +715,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             const bool over = act && C + add > CAP;
             if (__ballot(over) != 0) {
                 NSD_TIC();
-                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); }
+                // score_new covers every group of the wave; when it does not run, the groups that are not
+                // over keep their unscored tail
+                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
                 NSD_TOC(dbg_t_score);
-                scored = C;
                 NSD_TIC();
                 prune(over);
                 NSD_TOC(dbg_t_prune);

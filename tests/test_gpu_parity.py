@@ -564,6 +564,21 @@ def test_full_size_batch_properties(variant):
 
 
 @pytest.mark.gpu
+def test_two_utterances_per_wave_overflowing_at_different_times(dev):
+    """Beam 32 on 32 lanes per utterance, flat logits, a three-word lexicon with unspellable and multi-word
+    entries: nearly every hypothesis is in the top-k fall-back, the candidate buffer overflows several times per
+    step, and the two utterances that share a wave reach their overflows at different stages (one of them may
+    already be fully scored when the other one forces the scoring pass)."""
+    case = dict(variant="E", beam=32, lm_order=2, beta=0.0, margin=0.0, gamma=1.0, kappa=0.35, alpha=0.0,
+                min_len_for_eos=8, max_new_tokens=24, n_words=3, lex_seed=11, max_len=3, n_corpus=2000, corpus_seed=27,
+                n_utts=200, target_seed=79, base_seed=314692659, min_words=1, max_words=1, lanes=32, name="overflow32",
+                allow_eos_anytime=False, alphabet=synth.BASE_CHARS[:36], extra_words=["zq'x", "ice cream cone", "a b"])
+    ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)
+    assert err is None
+    _compare_with_trace(ws, ids, lens, scores, ref, case["name"])
+
+
+@pytest.mark.gpu
 def test_one_gpu_share_of_the_million_utterance_batch():
     """One GPU's share of the 1 000 000-utterance configuration over 8 GPUs (131 072 utterances, beam 16; the
     launcher then puts two utterances on a wave): slices of the batch decoded on their own (one utterance per
