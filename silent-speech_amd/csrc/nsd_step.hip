@@ -199,7 +199,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     if (__ballot(act) == 0) return;               // every utterance of this wave is finished or out of range
     NSD_STAMP(0);
 
-    auto gballot = [&](bool pred) -> uint64_t { return (__ballot(pred) >> gshift) & gmask; };
+    auto gballot = [&](bool pred) -> uint64_t { return (__builtin_amdgcn_ballot_w64(pred) >> gshift) & gmask; };
     // maximum over the wave's groups of a value that is uniform inside each group (scalar result)
     auto wave_max = [&](uint32_t v) -> uint32_t {
         uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
@@ -210,7 +210,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
         return m;
     };
-    auto gprefix = [&](uint64_t gb) -> uint32_t { return (uint32_t)__popcll(gb & ((1ull << gl) - 1ull)); };
+    // set bits of a group ballot below this lane (one utterance per wave: the wave-wide count instruction)
+    auto gprefix = [&](uint64_t gb) -> uint32_t {
+        if (UPW == 1)
+            return __builtin_amdgcn_mbcnt_hi((uint32_t)(gb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gb, 0u));
+        return (uint32_t)__popcll(gb & ((1ull << gl) - 1ull));
+    };
 
     const bool use_lm = P.use_lm != 0 && a.tab.order > 0;
     const int order = a.tab.order;
@@ -733,16 +738,18 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         if (pass == 0) NSD_STAMP(6);
         nsd_row_log_softmax5(x);
 
+        // lexicon-allowed characters: the predicate is one compare of the row's mask (0 when the row is
+        // not live) with the token's bit, so the ballot is that compare's result itself
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const uint32_t v = (uint32_t)(j * 5 + k);
-            const bool is_char = live && v < NSD_NBASE && ((mask >> v) & 1);
-            const bool is_eos = (v == NSD_EOS) && (eos_u || eos_e);
-            uint32_t w = v, kind = K_CHAR;
-            if (VARIANT == NSD_VARIANT_U) w = v + 1;
-            if (is_eos) { kind = K_EOS; w = (VARIANT == NSD_VARIANT_U) ? 0u : 40u; }
-            emit(is_char || is_eos, x[k], pack_info(v, kind, w, (uint32_t)r));
+            const uint64_t vbit = v < NSD_NBASE ? 1ull << v : 0ull;
+            emit((mask & vbit) != 0, x[k], pack_info(v, K_CHAR, (VARIANT == NSD_VARIANT_U) ? v + 1u : v, (uint32_t)r));
         }
+        // EOS option (variants U and E): token 38 is element 3 of the row's last lane
+        if (VARIANT != NSD_VARIANT_I)
+            emit((eos_u || eos_e) && j == 7, x[3],
+                 pack_info(NSD_EOS, K_EOS, (VARIANT == NSD_VARIANT_U) ? 0u : 40u, (uint32_t)r));
 
         // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
         if (__ballot(fb) != 0) {
