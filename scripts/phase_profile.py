@@ -62,6 +62,10 @@ for t in range(40):
                 print(f"      C in ({lo_},{hi_}]: {m.sum():5d} waves, duration mean {tot[m].mean():7.0f} max {tot[m].max():7.0f} | "
                       + "  ".join(f"{n.split('(')[0]} {d[m, i].mean():6.0f}" for i, n in enumerate(names)))
         # (clock values of different waves are not comparable: every XCD counts on its own)
+        slow = tot >= np.percentile(tot, 99)
+        print(f"      slowest 1 % of the waves ({slow.sum()}): candidates mean {Cc[slow].mean():.0f}  duration mean {tot[slow].mean():.0f} | "
+              + "  ".join(f"{n.split('(')[0]} {d[slow, i].mean():6.0f}" for i, n in enumerate(names))
+              + " | pass0 logits wait %.0f" % (s[act, 6] - s[act, 1])[slow].mean())
         pct = np.percentile(tot, [50, 90, 99, 100])
         print(f"   wave duration p50/p90/p99/max {pct.round()}  phase max: "
               + "  ".join(f"{n.split('(')[0]} {d[:,i].max():.0f}" for i, n in enumerate(names)))
