@@ -68,13 +68,40 @@ struct StepArgs {
     uint32_t     cap;            // candidate buffer entries per utterance
 };
 
+// One utterance's LDS region.  Hypothesis fields are interleaved in 104-byte records (one address per
+// hypothesis, fields at constant offsets); the candidate arrays follow at offsets that depend on the beam
+// and the buffer size only, so no per-array pointer has to be kept in registers.
 struct GroupLds {
-    double   *bScore, *bG, *bGe, *bBo, *bTermS;
-    uint64_t *bCtx, *bHist, *bMask, *bSym;
-    uint32_t *bChild, *bLmBase, *bMeta, *bNode, *bCtxId, *bCtxeId, *live, *sel, *total;
-    double   *cKey, *cScore, *sKey;
-    uint32_t *cInfo, *sIdx;
-    float    *rowbuf;
+    unsigned char *base;
+    uint32_t c_off, s_off, i_off, t_off;       // candidate keys, compaction arrays, candidate info words, total
+    uint32_t cap;
+    static constexpr uint32_t REC = 104;
+    template <class T> NSD_D T &rec(uint32_t p, uint32_t off) const { return *reinterpret_cast<T *>(base + p * REC + off); }
+    NSD_D double &bScore(uint32_t p) const { return rec<double>(p, 0); }
+    NSD_D double &bG(uint32_t p) const { return rec<double>(p, 8); }
+    NSD_D double &bGe(uint32_t p) const { return rec<double>(p, 16); }
+    NSD_D double &bBo(uint32_t p) const { return rec<double>(p, 24); }
+    NSD_D double &bTermS(uint32_t p) const { return rec<double>(p, 32); }
+    NSD_D uint64_t &bCtx(uint32_t p) const { return rec<uint64_t>(p, 40); }
+    NSD_D uint64_t &bHist(uint32_t p) const { return rec<uint64_t>(p, 48); }
+    NSD_D uint64_t &bMask(uint32_t p) const { return rec<uint64_t>(p, 56); }
+    NSD_D uint64_t &bSym(uint32_t p) const { return rec<uint64_t>(p, 64); }
+    NSD_D uint32_t &bChild(uint32_t p) const { return rec<uint32_t>(p, 72); }
+    NSD_D uint32_t &bLmBase(uint32_t p) const { return rec<uint32_t>(p, 76); }
+    NSD_D uint32_t &bMeta(uint32_t p) const { return rec<uint32_t>(p, 80); }
+    NSD_D uint32_t &bNode(uint32_t p) const { return rec<uint32_t>(p, 84); }
+    NSD_D uint32_t &bCtxId(uint32_t p) const { return rec<uint32_t>(p, 88); }
+    NSD_D uint32_t &bCtxeId(uint32_t p) const { return rec<uint32_t>(p, 92); }
+    NSD_D uint32_t &live(uint32_t p) const { return rec<uint32_t>(p, 96); }
+    NSD_D uint32_t &sel(uint32_t p) const { return rec<uint32_t>(p, 100); }
+    NSD_D double *cKey() const { return reinterpret_cast<double *>(base + c_off); }
+    NSD_D double *cScore() const { return reinterpret_cast<double *>(base + c_off + 8u * cap); }
+    NSD_D double *sKey() const { return reinterpret_cast<double *>(base + s_off); }
+    NSD_D float *rowbuf() const { return reinterpret_cast<float *>(base + s_off); }
+    NSD_D uint32_t *cInfo() const { return reinterpret_cast<uint32_t *>(base + i_off); }
+    NSD_D uint32_t *total() const { return reinterpret_cast<uint32_t *>(base + t_off); }
+    uint32_t sidx_off;
+    NSD_D uint32_t *sIdx() const { return reinterpret_cast<uint32_t *>(base + sidx_off); }
 };
 
 constexpr int BEAM_BYTES = 9 * 8 + 8 * 4;
@@ -91,34 +118,16 @@ template <int G>
 NSD_D GroupLds carve(unsigned char *base, int B, uint32_t cap, bool with_score)
 {
     GroupLds w;
-    unsigned char *p = base;
     B = (B + 1) & ~1;                              // keeps cKey / sKey 16-byte aligned (paired key reads)
-    w.bScore = (double *)p;   p += 8 * B;
-    w.bG     = (double *)p;   p += 8 * B;
-    w.bGe    = (double *)p;   p += 8 * B;
-    w.bBo    = (double *)p;   p += 8 * B;
-    w.bTermS = (double *)p;   p += 8 * B;
-    w.bCtx   = (uint64_t *)p; p += 8 * B;
-    w.bHist  = (uint64_t *)p; p += 8 * B;
-    w.bMask  = (uint64_t *)p; p += 8 * B;
-    w.bSym   = (uint64_t *)p; p += 8 * B;
-    w.cKey   = (double *)p;   p += 8 * (size_t)cap;
-    w.cScore = (double *)p;   if (with_score) p += 8 * (size_t)cap;
-    w.sKey   = (double *)p;   p += 8 * 2 * G;
-    w.sIdx   = (uint32_t *)p; p += 4 * 2 * G;
+    w.base = base;
+    w.cap = cap;
+    w.c_off = GroupLds::REC * (uint32_t)B;
+    w.s_off = w.c_off + 8u * cap * (with_score ? 2u : 1u);
     // the fall-back's row buffer (G/8 rows of 40 floats = 20 G bytes) shares the 24 G bytes of the
     // selection's compaction arrays: the two are never live at the same time
-    w.rowbuf = (float *)w.sKey;
-    w.cInfo  = (uint32_t *)p; p += 4 * (size_t)cap;
-    w.bChild = (uint32_t *)p; p += 4 * B;
-    w.bLmBase = (uint32_t *)p; p += 4 * B;
-    w.bMeta  = (uint32_t *)p; p += 4 * B;
-    w.bNode  = (uint32_t *)p; p += 4 * B;
-    w.bCtxId = (uint32_t *)p; p += 4 * B;
-    w.bCtxeId = (uint32_t *)p; p += 4 * B;
-    w.live   = (uint32_t *)p; p += 4 * B;
-    w.sel    = (uint32_t *)p; p += 4 * B;
-    w.total  = (uint32_t *)p; p += 16;
+    w.sidx_off = w.s_off + 8u * 2u * G;
+    w.i_off = w.s_off + 12u * 2u * G;
+    w.t_off = w.i_off + 4u * cap;
     return w;
 }
 
@@ -224,7 +233,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 
     // ---------------- phase 1: hypothesis state -> LDS ----------------
     bool my_live = false;
-    if (gl == 0) L.total[0] = 0;
+    if (gl == 0) L.total()[0] = 0;
     if (act && gl < nbeams) {
         const size_t i = (size_t)u * B + gl;
         const uint32_t meta = ld_meta;
@@ -266,20 +275,20 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint64_t mask = nrec.x;
         const uint32_t child = (uint32_t)nrec.y;
         if ((mask & ((1ull << NSD_NBASE) - 1)) == 0) mask = 0;     // nothing lexicon-consistent: fall-back
-        L.bScore[gl] = score; L.bG[gl] = G0; L.bGe[gl] = Ge; L.bBo[gl] = bo; L.bTermS[gl] = term_s;
-        L.bCtx[gl] = ctx; L.bHist[gl] = hist; L.bMask[gl] = mask; L.bSym[gl] = sym;
-        L.bChild[gl] = child; L.bLmBase[gl] = lmbase; L.bMeta[gl] = meta; L.bNode[gl] = node;
-        L.bCtxId[gl] = ctx_id; L.bCtxeId[gl] = ctxe_id;
+        L.bScore(gl) = score; L.bG(gl) = G0; L.bGe(gl) = Ge; L.bBo(gl) = bo; L.bTermS(gl) = term_s;
+        L.bCtx(gl) = ctx; L.bHist(gl) = hist; L.bMask(gl) = mask; L.bSym(gl) = sym;
+        L.bChild(gl) = child; L.bLmBase(gl) = lmbase; L.bMeta(gl) = meta; L.bNode(gl) = node;
+        L.bCtxId(gl) = ctx_id; L.bCtxeId(gl) = ctxe_id;
         if (a.mask_dbg) a.mask_dbg[i] = mask & ((1ull << NSD_NBASE) - 1);
         // upper bound of what this hypothesis adds to the candidate buffer
         uint32_t cnt = 1;                                          // carried unchanged
         if (my_live) cnt = mask ? (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + 1u
                                 : (uint32_t)(B < NSD_V ? B : NSD_V) + 1u;
-        atomicAdd(L.total, cnt);
+        atomicAdd(L.total(), cnt);
     }
     const uint64_t live_gb = gballot(my_live);
     const int nlive = __popcll(live_gb);
-    if (my_live) L.live[gprefix(live_gb)] = (uint32_t)gl;
+    if (my_live) L.live(gprefix(live_gb)) = (uint32_t)gl;
     nsd_wave_sync();
     NSD_STAMP(1);
 
@@ -301,8 +310,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         const uint64_t gb = gballot(pred);
         if (pred) {
             const uint32_t s = C + gprefix(gb);
-            L.cInfo[s] = info;
-            reinterpret_cast<float *>(L.cKey)[2 * s] = lp;
+            L.cInfo()[s] = info;
+            reinterpret_cast<float *>(L.cKey())[2 * s] = lp;
         }
         C += (uint32_t)__popcll(gb);
     };
@@ -315,11 +324,11 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         for (uint32_t rd = 0; rd < rounds; ++rd) {
             const uint32_t i = from + rd * G + gl;
             if (!(act && i < C)) continue;
-            const uint32_t info = L.cInfo[i];
+            const uint32_t info = L.cInfo()[i];
             const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = info >> 14;
-            const double lp = (double)reinterpret_cast<const float *>(L.cKey)[2 * i];
-            const double sb = L.bScore[p];
-            const uint32_t meta = L.bMeta[p];
+            const double lp = (double)reinterpret_cast<const float *>(L.cKey())[2 * i];
+            const double sb = L.bScore(p);
+            const uint32_t meta = L.bMeta(p);
             const int glen = (int)(meta >> 8);
             double score;
             int Lnew = glen + 1;
@@ -333,7 +342,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             } else {
                 const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
                 const int ms = 1 + glen - pend;
-                const bool whole = (L.bMask[p] >> 37) & 1;
+                const bool whole = (L.bMask(p) >> 37) & 1;
                 const bool is_eos = kind == K_EOS;
                 const bool is_sp = !is_eos && tok == NSD_SPACE;
                 double add = lp;
@@ -344,20 +353,20 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 s.full_new = false; s.term = 0.0;
                 double lgn = 0.0;
                 if (use_lm && !is_eos && (keep || !is_sp)) {
-                    const uint64_t ctx = L.bCtx[p];
+                    const uint64_t ctx = L.bCtx(p);
                     const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                    s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId[p], L.bSym[p], L.bLmBase[p], L.bBo[p], tok + 1u);
-                    lgn = L.bGe[p];
+                    s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId(p), L.bSym(p), L.bLmBase(p), L.bBo(p), tok + 1u);
+                    lgn = L.bGe(p);
                     if (s.has_int) lgn = lgn + s.lint;
                     if (keep) {
-                        L.cKey[CAP - 1u - i] = lgn;
-                        L.cInfo[CAP - 1u - i] = s.full_new ? s.next_id : NSD_CTX_NONE;
+                        L.cKey()[CAP - 1u - i] = lgn;
+                        L.cInfo()[CAP - 1u - i] = s.full_new ? s.next_id : NSD_CTX_NONE;
                     }
                 }
                 if (is_eos || is_sp) {
                     // both score the stripped surface: logp(surf + " ") == logp(surf)
-                    double lg = L.bG[p];
-                    if (ms + 1 >= order) lg = lg + L.bTermS[p];
+                    double lg = L.bG(p);
+                    if (ms + 1 >= order) lg = lg + L.bTermS(p);
                     if (is_eos) {                          // variant E boundary EOS (eval_ar.py:290-296)
                         add -= P.eos_len_nudge * (double)glen;
                         if (use_lm && glen > 0) add += P.beta * lg;
@@ -374,21 +383,21 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 score = sb + add;
             }
             if (VARIANT == NSD_VARIANT_E) {
-                L.cScore[i] = score;
-                L.cKey[i] = score / P.len_denom[Lnew];
+                L.cScore()[i] = score;
+                L.cKey()[i] = score / P.len_denom[Lnew];
             } else {
-                L.cKey[i] = score;
+                L.cKey()[i] = score;
             }
         }
     };
 
-    // top-`nsel` of candidates [0, C): afterwards L.sel[r] = buffer index of rank r (r < nsel), for the
+    // top-`nsel` of candidates [0, C): afterwards L.sel(r) = buffer index of rank r (r < nsel), for the
     // groups with `want`; every lane of the wave must call it
     auto select_top = [&](bool want, int nsel) {
-        if (want && gl < B) L.sel[gl] = SEL_NONE;
+        if (want && gl < B) L.sel(gl) = SEL_NONE;
         const uint32_t chunks = wave_max(want ? (C + G - 1) / G : 0u);   // buffer chunks of G candidates
         uint32_t F = want ? C : 0u;
-        const double *keys = L.cKey;
+        const double *keys = L.cKey();
         bool compacted = false, full_scan = false;
         // ---- threshold: at most fcap survivors, two per lane ----
         const uint32_t fcap = 2u * (uint32_t)G;
@@ -402,7 +411,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             for (int c = 0; c < KMAX; ++c) {
                 const uint32_t i = (uint32_t)c * G + gl;
                 kv[c] = in && i < C;
-                kk[c] = kv[c] ? L.cKey[i] : 0.0;
+                kk[c] = kv[c] ? L.cKey()[i] : 0.0;
             }
             // A bound from cell maxima first.  The lanes form `cells` >= nsel cells (every lane holds a
             // candidate, as C > G); the nsel-th best key is at least the smallest of the cells' best keys,
@@ -484,11 +493,11 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 if ((uint32_t)c >= chunks) continue;
                 const bool pred = ok && kv[c] && kk[c] >= tau;
                 const uint64_t gb = gballot(pred);
-                if (pred) { const uint32_t sidx = n + gprefix(gb); L.sKey[sidx] = kk[c]; L.sIdx[sidx] = (uint32_t)c * G + gl; }
+                if (pred) { const uint32_t sidx = n + gprefix(gb); L.sKey()[sidx] = kk[c]; L.sIdx()[sidx] = (uint32_t)c * G + gl; }
                 n += (uint32_t)__popcll(gb);
             }
             nsd_wave_sync();
-            if (ok) { keys = L.sKey; compacted = true; }
+            if (ok) { keys = L.sKey(); compacted = true; }
         } else if (__ballot(want && C > fcap) != 0) {
             bool searching = want && C > fcap;
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
@@ -502,7 +511,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 for (uint32_t ch = 0; ch < chunks && __ballot(searching && !have) != 0; ++ch) {
                     const uint32_t i = ch * G + gl;
                     const bool inb = searching && !have && i < C;
-                    const double k = inb ? L.cKey[i] : 0.0;
+                    const double k = inb ? L.cKey()[i] : 0.0;
                     const uint64_t gb = gballot(inb && k > lo && k < hi);
                     const bool pick = gb != 0 && searching && !have;
                     int src = lane;
@@ -517,7 +526,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 uint32_t c = 0;
                 for (uint32_t ch = 0; ch < chunks; ++ch) {
                     const uint32_t i = ch * G + gl;
-                    c += (uint32_t)__popcll(gballot(searching && have && i < C && L.cKey[i] >= pivot));
+                    c += (uint32_t)__popcll(gballot(searching && have && i < C && L.cKey()[i] >= pivot));
                 }
                 if (searching) {
                     if (!have) { full_scan = true; searching = false; }       // clustered / tied keys
@@ -531,14 +540,14 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             uint32_t n = 0;
             for (uint32_t ch = 0; ch < chunks; ++ch) {
                 const uint32_t i = ch * G + gl;
-                const double k = (ok && i < C) ? L.cKey[i] : 0.0;
+                const double k = (ok && i < C) ? L.cKey()[i] : 0.0;
                 const bool pred = ok && i < C && k >= tau;
                 const uint64_t gb = gballot(pred);
-                if (pred) { const uint32_t s = n + gprefix(gb); L.sKey[s] = k; L.sIdx[s] = i; }
+                if (pred) { const uint32_t s = n + gprefix(gb); L.sKey()[s] = k; L.sIdx()[s] = i; }
                 n += (uint32_t)__popcll(gb);
             }
             nsd_wave_sync();
-            if (ok) { keys = L.sKey; compacted = true; }
+            if (ok) { keys = L.sKey(); compacted = true; }
         }
         NSD_STAMP(9);
         // ---- rank among the F <= 2G survivors: two per lane ----
@@ -614,34 +623,34 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 }
             }
             const bool w0 = v0 && r0 < (uint32_t)nsel, w1 = v1 && r1 < (uint32_t)nsel;
-            if (w0) L.sel[r0] = compacted ? L.sIdx[f0] : f0;
-            if (w1) L.sel[r1] = compacted ? L.sIdx[f1] : f1;
+            if (w0) L.sel(r0) = compacted ? L.sIdx()[f0] : f0;
+            if (w1) L.sel(r1) = compacted ? L.sIdx()[f1] : f1;
             claimed = (uint32_t)__popcll(gballot(w0)) + (uint32_t)__popcll(gballot(w1));
         }
         nsd_wave_sync();
         // equal keys show up as a rank claimed twice: inside the top-B that leaves a hole, at its lower
         // edge it makes more claimants than places
-        const bool hole = want && gl < nsel && L.sel[gl] == SEL_NONE;
+        const bool hole = want && gl < nsel && L.sel(gl) == SEL_NONE;
         const bool redo = want && (full_scan || claimed != (uint32_t)nsel || gballot(hole) != 0);
         if (__ballot(redo) != 0) {
             NSD_COUNT(dbg_redo);
-            if (redo && gl < B) L.sel[gl] = SEL_NONE;
+            if (redo && gl < B) L.sel(gl) = SEL_NONE;
             nsd_wave_sync();
             const uint32_t Cmax = wave_max(redo ? C : 0u);
             for (uint32_t ch = 0; ch < chunks; ++ch) {
                 const uint32_t i = ch * G + gl;
                 const bool valid = redo && i < C;
-                const double mk = valid ? L.cKey[i] : 0.0;
-                const uint32_t mo = valid ? ((L.cInfo[i] >> 8) & 0xFFFu) : 0u;
+                const double mk = valid ? L.cKey()[i] : 0.0;
+                const uint32_t mo = valid ? ((L.cInfo()[i] >> 8) & 0xFFFu) : 0u;
                 uint32_t rank = 0;
                 for (uint32_t q = 0; q < Cmax; ++q) {
                     if (redo && q < C) {
-                        const double k = L.cKey[q];
-                        const uint32_t o = (L.cInfo[q] >> 8) & 0xFFFu;
+                        const double k = L.cKey()[q];
+                        const uint32_t o = (L.cInfo()[q] >> 8) & 0xFFFu;
                         rank += (k > mk || (k == mk && (o < mo || (o == mo && q < i)))) ? 1u : 0u;
                     }
                 }
-                if (valid && rank < (uint32_t)nsel) L.sel[rank] = i;
+                if (valid && rank < (uint32_t)nsel) L.sel(rank) = i;
             }
             nsd_wave_sync();
         }
@@ -655,14 +664,14 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint32_t info = 0;
         double key = 0.0, sc = 0.0;
         if (over && gl < keep) {
-            const uint32_t s = L.sel[gl];
-            info = L.cInfo[s]; key = L.cKey[s];
-            if (VARIANT == NSD_VARIANT_E) sc = L.cScore[s];
+            const uint32_t s = L.sel(gl);
+            info = L.cInfo()[s]; key = L.cKey()[s];
+            if (VARIANT == NSD_VARIANT_E) sc = L.cScore()[s];
         }
         nsd_wave_sync();
         if (over && gl < keep) {
-            L.cInfo[gl] = info; L.cKey[gl] = key;
-            if (VARIANT == NSD_VARIANT_E) L.cScore[gl] = sc;
+            L.cInfo()[gl] = info; L.cKey()[gl] = key;
+            if (VARIANT == NSD_VARIANT_E) L.cScore()[gl] = sc;
         }
         if (over) C = (uint32_t)keep;
         nsd_wave_sync();
@@ -671,7 +680,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // finished hypotheses compete unchanged (ns_utils.py:222-224); they are scored with the first pass
     emit(act && gl < nbeams && !my_live, 0.0f, pack_info(0x3f, K_CARRY, 0, (uint32_t)gl));
     // when everything the step can emit fits the buffer (the usual case) no pass needs an overflow check
-    const bool may_overflow = __ballot(act && L.total[0] > CAP) != 0;
+    const bool may_overflow = __ballot(act && L.total()[0] > CAP) != 0;
 
     // ---------------- passes: log-softmax, candidates, scores ----------------
     const int j = lane & 7;
@@ -683,7 +692,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     auto fetch_row = [&](int pass) {
         const int slot = pass * RPP + (gl >> 3);
         if (act && slot < nlive) {
-            const float *row = a.logits + ((size_t)u * B + (int)L.live[slot]) * NSD_V + j * 5;
+            const float *row = a.logits + ((size_t)u * B + (int)L.live(slot)) * NSD_V + j * 5;
 #pragma unroll
             for (int k = 0; k < 5; ++k) xn[k] = row[k];
         } else {
@@ -695,9 +704,9 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     for (int pass = 0; pass < npass_max; ++pass) {
         const int slot = pass * RPP + (gl >> 3);
         const bool live = act && slot < nlive;
-        const int r = live ? (int)L.live[slot] : 0;
-        const uint32_t meta = L.bMeta[r];
-        const uint64_t mask = live ? L.bMask[r] : 0;
+        const int r = live ? (int)L.live(slot) : 0;
+        const uint32_t meta = L.bMeta(r);
+        const uint64_t mask = live ? L.bMask(r) : 0;
         const int glen = (int)(meta >> 8);
         const bool whole = (mask >> 37) & 1;
         const bool pend = (meta & NSD_F_PENDING_SPACE) != 0;
@@ -753,7 +762,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 
         // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
         if (__ballot(fb) != 0) {
-            float *rb = L.rowbuf + (gl >> 3) * NSD_V;
+            float *rb = L.rowbuf() + (gl >> 3) * NSD_V;
 #pragma unroll
             for (int k = 0; k < 5; ++k) rb[j * 5 + k] = x[k];
             nsd_wave_sync();
@@ -800,19 +809,19 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // ---------------- write the surviving hypotheses ----------------
     bool fin = true;
     if (act && gl < nsel) {
-        uint32_t mysel = L.sel[gl];
+        uint32_t mysel = L.sel(gl);
         if (mysel >= C) mysel = 0;                 // only reachable with NaN keys
-        const uint32_t info = L.cInfo[mysel];
+        const uint32_t info = L.cInfo()[mysel];
         const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = (info >> 14) & 0x3f;
-        const double score = (VARIANT == NSD_VARIANT_E) ? L.cScore[mysel] : L.cKey[mysel];
-        uint32_t meta = L.bMeta[p];
+        const double score = (VARIANT == NSD_VARIANT_E) ? L.cScore()[mysel] : L.cKey()[mysel];
+        uint32_t meta = L.bMeta(p);
         uint32_t flags = meta & 0xffu;
         int glen = (int)(meta >> 8);
-        double G0 = L.bG[p], Ge = L.bGe[p];
-        uint64_t ctx = L.bCtx[p];
-        uint64_t hist = L.bHist[p];
-        uint32_t node = L.bNode[p];
-        uint32_t ctx_id = L.bCtxId[p], ctxe_id = L.bCtxeId[p];
+        double G0 = L.bG(p), Ge = L.bGe(p);
+        uint64_t ctx = L.bCtx(p);
+        uint64_t hist = L.bHist(p);
+        uint32_t node = L.bNode(p);
+        uint32_t ctx_id = L.bCtxId(p), ctxe_id = L.bCtxeId(p);
         uint8_t out_tok = NSD_TOKEN_CARRY;
         if (kind != K_CARRY) {
             out_tok = (uint8_t)tok;
@@ -829,11 +838,11 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 // and prepare the effective one (context + space).  A hypothesis with a pending space
                 // sits at the trie root, which never allows a space, so pend == 0 here.
                 if (use_lm && kept) {
-                    Ge = L.cKey[CAP - 1u - mysel];
-                    ctxe_id = L.cInfo[CAP - 1u - mysel];
+                    Ge = L.cKey()[CAP - 1u - mysel];
+                    ctxe_id = L.cInfo()[CAP - 1u - mysel];
                 } else if (use_lm) {
-                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctx, ctx_id, L.bSym[p], L.bLmBase[p],
-                                                       L.bBo[p], NSD_SPACE + 1u);
+                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctx, ctx_id, L.bSym(p), L.bLmBase(p),
+                                                       L.bBo(p), NSD_SPACE + 1u);
                     Ge = s.has_int ? G0 + s.lint : G0;
                     ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
                 }
@@ -842,21 +851,21 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             } else {
                 if (use_lm && kept) {
                     const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                    G0 = Ge = L.cKey[CAP - 1u - mysel];
+                    G0 = Ge = L.cKey()[CAP - 1u - mysel];
                     ctx = nsd_ctx_shift(a.tab, ctxe, tok + 1u);
-                    ctx_id = ctxe_id = L.cInfo[CAP - 1u - mysel];
+                    ctx_id = ctxe_id = L.cInfo()[CAP - 1u - mysel];
                 } else if (use_lm) {
                     const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, ctxe_id, L.bSym[p], L.bLmBase[p],
-                                                       L.bBo[p], tok + 1u);
+                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, ctxe_id, L.bSym(p), L.bLmBase(p),
+                                                       L.bBo(p), tok + 1u);
                     G0 = s.has_int ? Ge + s.lint : Ge;
                     Ge = G0;
                     ctx = s.ctxn;
                     ctx_id = ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
                 }
                 flags &= ~NSD_F_PENDING_SPACE;
-                const uint64_t m = L.bMask[p];
-                node = L.bChild[p] + (uint32_t)__popcll(m & ((1ull << tok) - 1ull) & ((1ull << 36) - 1ull));
+                const uint64_t m = L.bMask(p);
+                node = L.bChild(p) + (uint32_t)__popcll(m & ((1ull << tok) - 1ull) & ((1ull << 36) - 1ull));
             }
             glen += 1;
         }
