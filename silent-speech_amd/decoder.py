@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import lib as _lib
+from .text import finish_transcripts, ids_to_text  # noqa: F401  (ids_to_text: scripts/ns_utils.py:284-296)
 from .tables import (BASE_CHARS, BOS_ID, EOS_ID, PAD_ID, VOCAB, HostTrie, NgramTables, compile_ngram,
                      flatten_trie)
 
@@ -345,16 +346,22 @@ def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, l
     return hyps[0]
 
 
-def ids_to_text(TT, ids: Sequence[int]) -> str:
-    """scripts/ns_utils.py:284-296."""
-    out = []
-    for i in ids[1:]:
-        if i == TT.EOS_IDX:
-            break
-        j = i - TT.VOCAB_OFFSET
-        if 0 <= j < len(TT.BASE_CHARS):
-            out.append(TT.BASE_CHARS[j])
-    return "".join(out).strip()
+def transcribe_batch(TT, ar_ids: torch.Tensor, ar_len: torch.Tensor, tables: "DeviceTables", is_word,
+                     lex_words: Sequence[str], ctc_logits: Optional[torch.Tensor] = None) -> List[str]:
+    """Final transcripts of a decoded batch as the driver produces them (inference_emg_llm.py:436-464): AR ids ->
+    text -> postprocess; with ``ctc_logits`` [N, T', 40] also the CTC greedy proposal (on the GPU) and the LM
+    choice between the two.  The LM scores come from the same tables the decoder used."""
+    from .tables import host_logp
+    ctc_ids = ctc_len = None
+    logp = None
+    if ctc_logits is not None:
+        if tables.ngram is None:
+            raise ValueError("the CTC rerank needs n-gram tables")
+        ci, cl = ctc_greedy_batch(ctc_logits)
+        ctc_ids, ctc_len = ci.cpu().numpy(), cl.cpu().numpy()
+        logp = lambda s: host_logp(tables.ngram, s)          # noqa: E731
+    return finish_transcripts(TT, ar_ids.cpu().numpy(), ar_len.cpu().numpy(), is_word, lex_words, logp,
+                              ctc_ids, ctc_len)
 
 
 # ----------------------------------------------------------------------

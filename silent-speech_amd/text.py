@@ -53,3 +53,44 @@ def build_lexicon(texts: Iterable[str], min_freq: int = 1, min_len: int = 1, max
         extras = [w for w in extras if all(ch in allowed for ch in w)]
         words = list(dict.fromkeys(words + extras))
     return words
+
+
+def ids_to_text(TT, ids: Sequence[int]) -> str:
+    """scripts/ns_utils.py:284-296: skip ids[0], stop at EOS, keep base characters, strip."""
+    out = []
+    for i in ids[1:]:
+        if i == TT.EOS_IDX:
+            break
+        j = i - TT.VOCAB_OFFSET
+        if 0 <= j < len(TT.BASE_CHARS):
+            out.append(TT.BASE_CHARS[j])
+    return "".join(out).strip()
+
+
+def rerank_by_lm(hyp_ar: str, hyp_ctc: str, logp) -> str:
+    """The driver's choice between the AR and the CTC transcript (inference_emg_llm.py:457-464):
+    ``logp(s) - 0.002 * len(s)``, the AR transcript wins ties (first maximal element)."""
+    def score(s: str) -> float:
+        return float(logp(s)) - 0.002 * len(s)
+    return max([(hyp_ar, score(hyp_ar)), (hyp_ctc, score(hyp_ctc))], key=lambda c: c[1])[0]
+
+
+def finish_transcripts(TT, ar_ids, ar_len, is_word, lex_words: Sequence[str], logp=None,
+                       ctc_ids=None, ctc_len=None) -> List[str]:
+    """What the driver does with one utterance after the beam search (inference_emg_llm.py:436-464), for a
+    batch: ``ids_to_text`` + ``postprocess`` of the AR ids and, when collapsed CTC ids are given
+    (``--use_ctc_rerank``), the same for the CTC proposal wrapped in BOS/EOS and the LM choice between the
+    two.  ``ar_ids`` [N, >=len] starts with BOS; ``ctc_ids`` [N, >=len] holds the ids ``ctc_greedy_batch``
+    returns (repeats collapsed, PAD/BOS/EOS dropped).  ``logp`` is ``lm.logp`` (any callable str -> float).
+    Rows may be numpy arrays, tensors moved to the host, or lists."""
+    out: List[str] = []
+    for u in range(len(ar_len)):
+        hyp = postprocess(ids_to_text(TT, [int(t) for t in ar_ids[u][:int(ar_len[u])]]), is_word, lex_words)
+        if ctc_ids is not None:
+            if logp is None:
+                raise ValueError("the CTC rerank needs the LM's logp")
+            ids = [TT.BOS_IDX] + [int(t) for t in ctc_ids[u][:int(ctc_len[u])]] + [TT.EOS_IDX]
+            hyp_ctc = postprocess(ids_to_text(TT, ids), is_word, lex_words)
+            hyp = rerank_by_lm(hyp, hyp_ctc, logp)
+        out.append(hyp)
+    return out

@@ -432,6 +432,17 @@ def test_ctc_proposal_and_lm_rerank_pipeline(dev):
         assert float(scores[u, 1]).hex() == (float(lm.logp(hyp_ctc)) - 0.002 * len(hyp_ctc)).hex()
         n_ctc += int(choice[u])
     assert 0 < n_ctc < len(targets)
+    # the driver's whole tail, postprocess included (inference_emg_llm.py:436-464)
+    from silent_speech_amd.decoder import transcribe_batch
+    from silent_speech_amd import TextTransform
+    trie = O.build_trie(words)
+    final = transcribe_batch(TextTransform, ar_ids, ar_len, tables, trie, words, ctc_logits=torch.from_numpy(x).to(dev))
+    plain = transcribe_batch(TextTransform, ar_ids, ar_len, tables, trie.is_word, words)
+    for u in range(len(targets)):
+        hyp_ar = O.postprocess(O.ids_to_text(TT, ar_np[u, :al[u]].tolist()), trie, words)
+        hyp_ctc = O.postprocess(O.ctc_hypothesis(x[u], TT), trie, words)
+        assert plain[u] == hyp_ar, u
+        assert final[u] == O.rerank_lm(hyp_ar, hyp_ctc, lm), u
 
 
 # ---------------------------------------------------------------------------
