@@ -22,7 +22,7 @@ def __getattr__(name):
     # decoder.py needs torch; keep `import silent_speech_amd` light for table-only users
     if name in ("DeviceTables", "NSDecoder", "Workspace", "constrained_beam_decode", "ids_to_text",
                 "ctc_greedy_batch", "lm_logp_batch", "rerank_gather_batch", "log_softmax_rows", "rerank_lm_batch",
-                "transcribe_batch"):
+                "transcribe_batch", "transcribe_batch_joint"):
         from . import decoder
         return getattr(decoder, name)
     raise AttributeError(name)

@@ -416,6 +416,48 @@ def rerank_gather_batch(logits: torch.Tensor, target: torch.Tensor, lens: torch.
     return out[:N]
 
 
+def transcribe_batch_joint(TT, ar_ids: torch.Tensor, ar_len: torch.Tensor, tables: "DeviceTables", is_word,
+                           lex_words: Sequence[str], ctc_logits: torch.Tensor, teacher_logits: Callable,
+                           lm_weight: float):
+    """The tail of eval_ar.py for a batch (eval_ar.py:546-596): AR and CTC transcripts, post-processed, then the
+    joint choice ``ar_logprob(s) + lm_weight * lm.logp(s)`` with the AR transcript winning ties.
+
+    ``teacher_logits(seq u8 [M, L], lens i32 [M]) -> float32 [M, L-1, 40]`` on the device: row i of sequence m
+    holds the logits after the prefix ``seq[m, :i+1]`` (what ``step_fn(seq[:i+1])`` returns), for the 2N
+    sequences BOS + characters + EOS of the candidates.  Returns (transcripts, scores f64 [N, 2])."""
+    from .tables import host_logp
+    ci, cl = ctc_greedy_batch(ctc_logits)
+    ci, cl = ci.cpu().numpy(), cl.cpu().numpy()
+    ar_np, al = ar_ids.cpu().numpy(), ar_len.cpu().numpy()
+    N = len(al)
+    hyp_ar = finish_transcripts(TT, ar_np, al, is_word, lex_words)
+    wrapped = [[TT.BOS_IDX] + [int(t) for t in ci[u][:int(cl[u])]] + [TT.EOS_IDX] for u in range(N)]
+    hyp_ctc = finish_transcripts(TT, wrapped, [len(w) for w in wrapped], is_word, lex_words)
+    cands = hyp_ar + hyp_ctc
+    seqs = [[TT.BOS_IDX] + [TT.VOCAB_OFFSET + TT.BASE_CHARS.index(c) for c in s if c in TT.BASE_CHARS] + [TT.EOS_IDX]
+            for s in cands]
+    L = max(len(q) for q in seqs)
+    seq = np.full((2 * N, L), TT.PAD_IDX, np.uint8)
+    lens = np.zeros(2 * N, np.int32)
+    for m, q in enumerate(seqs):
+        seq[m, :len(q)] = q
+        lens[m] = len(q)
+    dev = ctc_logits.device
+    seq_d, lens_d = torch.from_numpy(seq).to(dev), torch.from_numpy(lens).to(dev)
+    logits = teacher_logits(seq_d, lens_d)
+    if logits.shape != (2 * N, L - 1, VOCAB) or logits.dtype != torch.float32:
+        raise ValueError("teacher_logits must return float32 [2N, L-1, 40]")
+    ar_lp = rerank_gather_batch(logits.contiguous(), seq_d[:, 1:].contiguous(), lens_d - 1).cpu().numpy()
+    scores = np.zeros((N, 2), np.float64)
+    out = []
+    for u in range(N):
+        for c, s in ((0, hyp_ar[u]), (1, hyp_ctc[u])):
+            part = host_logp(tables.ngram, s) if tables.ngram is not None else 0.0
+            scores[u, c] = (float(ar_lp[u + c * N]) if s else -1e9) + lm_weight * part      # eval_ar.py:575-576,591-593
+        out.append(hyp_ctc[u] if scores[u, 1] > scores[u, 0] else hyp_ar[u])
+    return out, scores
+
+
 def log_softmax_rows(x: torch.Tensor) -> torch.Tensor:
     """The decoder's deterministic fp32 log-softmax over the last dim (=40)."""
     _require_cuda()

@@ -445,6 +445,68 @@ def test_ctc_proposal_and_lm_rerank_pipeline(dev):
         assert final[u] == O.rerank_lm(hyp_ar, hyp_ctc, lm), u
 
 
+@pytest.mark.gpu
+def test_joint_rerank_tail_of_the_evaluation_driver(dev):
+    """eval_ar.py:546-596 for a batch: AR decode (variant E), CTC proposal, postprocess of both, then the choice by
+    teacher-forced AR log-prob + beta * LM log-prob.  The AR head is the synthetic one (a function of the token
+    history), evaluated on the host for every prefix of both candidates; checked against the restatement with the
+    same deterministic log-softmax (choice identical, scores to 1e-12 relative)."""
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder, transcribe_batch_joint
+    from silent_speech_amd import TextTransform
+    TT = O.TextTransformLike
+    words = synth.make_lexicon(120, 3, max_len=7)
+    corpus = synth.make_sentences(words, 3000, 1)
+    targets = synth.make_sentences(words, 48, 21, 2, 4)
+    tg, tl = _pack_targets(targets)
+    lm = O.NgramLM(3, floor_vsz=False).fit(corpus)
+    tables = DeviceTables.from_words(words, lm)
+    beta, margin, seed = 0.3, 6.0, 12
+    dec = NSDecoder(tables, 8, 32, variant="E", lm_weight=beta, oov_penalty=1.0, word_bonus=0.35)
+    ar_ids, ar_len, _ = dec.decode_synth_native(torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev),
+                                                base_seed=seed, margin=margin)
+    rng = np.random.RandomState(2)
+    Tp = 120
+    x = rng.randn(len(targets), Tp, 40).astype(np.float32)
+    for u, t in enumerate(targets):
+        toks = synth.text_to_tokens(t)[: Tp // 3]
+        if u % 4 == 0 and len(toks) > 3:
+            toks[2] = (toks[2] + 1) % 26                              # a wrong letter in the CTC stream
+        f = 0
+        for tok in toks:
+            x[u, f:f + 2, tok] += 8.0; x[u, f + 2, 39] += 8.0; f += 3
+        x[u, f:, 39] += 8.0
+    N = len(targets)
+    tgt_tokens = [synth.text_to_tokens(t) for t in targets]
+
+    def step_row(u, ids):
+        return synth.logits_row(synth.utt_seed(seed, u), ids, tgt_tokens[u], margin)
+
+    def teacher_logits(seq, lens):
+        sq, ln = seq.cpu().numpy(), lens.cpu().numpy()
+        out = np.zeros((sq.shape[0], sq.shape[1] - 1, 40), np.float32)
+        for m in range(sq.shape[0]):
+            for i in range(1, ln[m]):
+                out[m, i - 1] = step_row(m % N, sq[m, :i].tolist())
+        return torch.from_numpy(out).to(seq.device)
+
+    trie = O.build_trie(words)
+    final, scores = transcribe_batch_joint(TextTransform, ar_ids, ar_len, tables, trie, words,
+                                           torch.from_numpy(x).to(dev), teacher_logits, beta)
+    ar_np, al = ar_ids.cpu().numpy(), ar_len.cpu().numpy()
+    n_ctc = 0
+    for u in range(N):
+        hyp_ar = O.postprocess(O.ids_to_text(TT, ar_np[u, :al[u]].tolist()), trie, words)
+        hyp_ctc = O.postprocess(O.ctc_hypothesis(x[u], TT), trie, words)
+        step_fn = lambda ids, u=u: step_row(u, ids)                  # noqa: E731
+        want = O.rerank_joint(hyp_ar, hyp_ctc, step_fn, TT, lm, beta, O.lsm_det)
+        assert final[u] == want, (u, hyp_ar, hyp_ctc, scores[u])
+        for c, sxt in ((0, hyp_ar), (1, hyp_ctc)):
+            ref = O.ar_logprob(sxt, step_fn, TT, O.lsm_det) + beta * float(lm.logp(sxt))
+            assert abs(scores[u, c] - ref) <= 1e-12 * max(1.0, abs(ref)), (u, c)
+        n_ctc += int(final[u] != hyp_ar)
+    assert n_ctc > 0
+
+
 # ---------------------------------------------------------------------------
 # next-character prior and the training regulariser
 # ---------------------------------------------------------------------------
