@@ -14,11 +14,18 @@ by the copy of the NS decoder that inference_emg_llm.py itself calls (variant
 I, inference_emg_llm.py:222-300: no EOS option, so every utterance runs all
 T_max = 64 steps with 16 live hypotheses), beta 0.05, gamma 1.0, planted-target
 margin 60.  The scripts/ns_utils.py copy (variant U, EOS offered at every
-step) is measured in the same run and reported under "variant_U".  With
---gpus N every rank decodes its own 4096-utterance shard (weak scaling) and
-rank 0 gathers the ids.
+step) is measured in the same run and reported under "variant_U".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+Several GPUs: utterances are independent, so rank r decodes its own contiguous
+block with a replica of the tables and rank 0 gathers the ids (one collective
+per decode).  --gpus N without WORLD_SIZE in the environment starts the N
+ranks itself (fresh child processes; the parent touches no GPU); under
+torchrun the ranks are taken from the environment.  Default: every rank
+decodes --utts utterances (weak scaling).  --utts-total M splits M utterances
+of the global numbering over the ranks (strong scaling, the 1M-utterance
+configuration): rank r decodes shard_range(M, r, N).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--utts-total M]
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,36 +38,65 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+
+# numpy and torch are imported by worker(): the launching parent of a multi-GPU run needs neither
+np = None
+torch = None
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (spec)
 VARIANT_SRC = {"U": "scripts/ns_utils.py:194", "I": "inference_emg_llm.py:222", "E": "eval_ar.py:214"}
 
 
 def build_workload(n_utts: int, utt0: int, lex_words: int, corpus_n: int, order: int, open_lexicon: bool):
-    """Seeded lexicon / corpus / planted targets."""
+    """Seeded lexicon / corpus / planted targets of the utterances [utt0, utt0 + n_utts) of the global numbering."""
     from silent_speech_amd import synthetic as synth
     if open_lexicon:
         words = synth.make_lexicon(lex_words, 1, synth.BASE_CHARS[:36], 2, 12)
     else:
         words = synth.make_lexicon(lex_words, 0, synth.BASE_CHARS[:26], 2, 8)
     corpus = synth.make_sentences(words, corpus_n, 1)
-    # targets are drawn per global utterance block so that ranks decode different utterances
-    targets = synth.make_sentences(words, n_utts, 1000 + utt0 // max(n_utts, 1), 3, 7)
+    targets = synth.targets_for_range(words, utt0, utt0 + n_utts)
     tg, tl = synth.pack_targets(targets)
     return words, corpus, targets, tg, tl
 
 
-def popcount64(a: np.ndarray) -> np.ndarray:
-    a = a.astype(np.uint64)
-    a = a - ((a >> np.uint64(1)) & np.uint64(0x5555555555555555))
-    a = (a & np.uint64(0x3333333333333333)) + ((a >> np.uint64(2)) & np.uint64(0x3333333333333333))
-    a = (a + (a >> np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
-    return ((a * np.uint64(0x0101010101010101)) >> np.uint64(56)).astype(np.int64)
+def decoded_text_stats(ids_np, lens_np, tg, tl):
+    """Per utterance, from the decoded ids (BOS first): number of characters of ids_to_text(ids)
+    (scripts/ns_utils.py:284-296: skip BOS, stop at EOS, keep base characters, strip), whether that text equals
+    the planted target and whether it starts with it.  Vectorised (a 1M-utterance shard is one call)."""
+    n, W = ids_np.shape
+    col = np.arange(W)[None, :]
+    valid = (col >= 1) & (col < lens_np[:, None])
+    eos = valid & (ids_np == 38)
+    first_eos = np.where(eos.any(1), eos.argmax(1), W)
+    keep = valid & (col < first_eos[:, None]) & (ids_np < 37)
+    nonsp = keep & (ids_np != 36)
+    any_ns = nonsp.any(1)
+    first = np.where(any_ns, nonsp.argmax(1), W)
+    last = np.where(any_ns, W - 1 - nonsp[:, ::-1].argmax(1), -1)
+    text = keep & (col >= first[:, None]) & (col <= last[:, None])
+    nchar = text.sum(1)
+    # position of every text character inside its text, compared with the target at that position
+    pos = np.cumsum(text, 1) - 1
+    S = tg.shape[1]
+    tpos = np.clip(pos, 0, S - 1)
+    tchar = np.take_along_axis(tg.astype(np.int16), tpos, 1)
+    in_target = pos < tl[:, None]
+    mism = text & in_target & (tchar != ids_np)
+    starts = (~mism.any(1)) & (nchar >= tl)
+    exact = starts & (nchar == tl)
+    return nchar.astype(np.int64), exact, starts
+
+
+def popcount64_t(a):
+    """Set bits of every int64 element (device tensor)."""
+    m1, m2, m4 = 0x5555555555555555, 0x3333333333333333, 0x0F0F0F0F0F0F0F0F
+    a = a - ((a >> 1) & m1)
+    a = (a & m2) + ((a >> 2) & m2)
+    a = (a + (a >> 4)) & m4
+    return ((a * 0x0101010101010101) >> 56) & 0xFF
 
 
 def algorithmic_bytes(dec, tgd, tld, args):
@@ -69,19 +105,30 @@ def algorithmic_bytes(dec, tgd, tld, args):
     Per live hypothesis the scorer must move: its 40 fp32 logits (160 B), its state in and out, its trie
     node record, back-pointer and token (245 B in all), and two table slots (interior + terminal n-gram)
     for each allowed child and for the hypothesis itself: 245 + 32 * (c + 1) bytes.
+    The step loop is driven from here, one launch at a time; the lexicon masks of each step go to one reused
+    buffer and are counted on the device (a 1M-utterance shard needs no [T, N*B] mask array).
     """
-    ws = dec.workspace(tgd.shape[0], with_masks=True)
-    ws.token.fill_(0xFF)
-    dec.decode_synth(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0, ws=ws, check_every=1)
-    torch.cuda.synchronize()
-    T, N, B = ws.steps_run, ws.N, ws.B
-    tok = ws.token[:T].cpu().numpy()
-    masks = ws.masks[:T].cpu().numpy().view(np.uint64)
-    live = np.zeros(T, np.int64)
-    live[0] = N
-    for t in range(1, T):
-        live[t] = int(((tok[t - 1] != 0xFF) & (tok[t - 1] != 38)).sum())
-    cands = np.array([int(popcount64(masks[t] & np.uint64((1 << 37) - 1)).sum()) for t in range(T)], np.int64)
+    ws = dec.workspace(tgd.shape[0], with_masks=False)
+    masks = torch.zeros(max(ws.N * ws.B, 1), dtype=torch.int64, device=ws.score.device)
+    dec.init(ws)
+    live, cands = [], []
+    low37 = (1 << 37) - 1
+    for t in range(dec.T):
+        masks.zero_()
+        dec.synth_logits(ws, args.seed, args.utt0, tgd, tld, args.margin)
+        um = ws.utt[:ws.N].to(torch.int64)
+        meta = ws.meta[:ws.N * ws.B].view(ws.N, ws.B)
+        nb = (um & 0xFF).view(-1, 1)
+        is_live = ((torch.arange(ws.B, device=meta.device).view(1, -1) < nb) & ((meta & 1) == 0)
+                   & ((um & 0x100) == 0).view(-1, 1))
+        n_live = int(is_live.sum().item())
+        dec.step(ws, mask_out=masks)
+        live.append(n_live)
+        cands.append(int(popcount64_t(masks & low37).sum().item()))
+        if dec.all_done(ws):
+            break
+    T = len(live)
+    live, cands = np.array(live, np.int64), np.array(cands, np.int64)
     per_step = live * 245 + 32 * (cands + live)
     return T, live, cands, per_step
 
@@ -90,6 +137,7 @@ def cpu_baseline(words, corpus, targets, args, gpu_texts):
     """The reference algorithm on one host core: the Python restatement (oracle/ns_oracle.py: dict trie,
     whole-string n-gram score per candidate, one step_fn call and one torch log_softmax per live
     hypothesis, stable sort) on a bounded sample of the same utterances."""
+    import torch
     from oracle import ns_oracle as O, synth
     torch.set_num_threads(1)
     trie = O.build_trie(words)
@@ -121,6 +169,7 @@ def cpu_baseline(words, corpus, targets, args, gpu_texts):
 def _cpu_shard(job):
     """Worker of the all-cores CPU figure: decodes its own utterances until the time is up."""
     (words, corpus, targets, u_first, seed, utt0, margin, beam, tmax, order, variant, beta, gamma, kappa, seconds) = job
+    import torch
     from oracle import ns_oracle as O, synth
     torch.set_num_threads(1)
     trie = O.build_trie(words)
@@ -160,11 +209,46 @@ def cpu_all_cores(words, corpus, targets, args):
                       f"after start-up)"}
 
 
-def secondary_variant(args, variant, words, corpus, tgd, tld, targets):
+def timed_launches(dec, ws, tgd, tld, args, reps):
+    """nsd_step launch durations (seconds, one row per decode) from HIP events on the launch stream, taken on
+    decodes of their own, outside any throughput window."""
+    sm = np.zeros(max(args.tmax, 1), np.float32)
+    rows = []
+    for _ in range(reps):
+        dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0,
+                                check_every=args.check_every, ws=ws, step_ms=sm)
+        rows.append(sm[:ws.steps_run].astype(np.float64) * 1e-3)
+    n = min(len(r) for r in rows)
+    return np.stack([r[:n] for r in rows])
+
+
+def roofline_of(per_step, live, cands, d, steps_run):
+    """HBM roofline of nsd_step: algorithmic bytes per launch over the mean event duration of a launch."""
+    if len(per_step) < steps_run:               # launches after every utterance finished move no bytes
+        pad = steps_run - len(per_step)
+        per_step = np.concatenate([per_step, np.zeros(pad, np.int64)])
+        live = np.concatenate([live, np.zeros(pad, np.int64)])
+        cands = np.concatenate([cands, np.zeros(pad, np.int64)])
+    per_step = per_step[:steps_run]
+    bytes_per_launch = float(per_step.sum()) / max(steps_run, 1)
+    avg = float(d.mean())
+    achieved = bytes_per_launch / avg / 1e9
+    per_launch = d.mean(0)
+    k = min(len(per_launch), len(per_step))
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "nsd_step_kernel",
+            "launches_timed": int(d.size), "avg_launch_us": avg * 1e6,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "mean_live_hyps_per_launch": float(live[:steps_run].sum() / max(steps_run, 1)),
+            "mean_children_per_live_hyp": float(cands[:steps_run].sum() / max(live[:steps_run].sum(), 1)),
+            "busiest_launch": {"us": float(per_launch.max() * 1e6),
+                               "GBps": float((per_step[:k] / np.maximum(per_launch[:k], 1e-9)).max() / 1e9)}}
+
+
+def secondary_variant(args, variant, words, corpus, tgd, tld, tg, tl):
     """Same batch through another copy of the decoder: chars/s and the nsd_step roofline, briefly."""
     import copy
-    from silent_speech_amd.decoder import DeviceTables, NSDecoder, ids_to_text
-    from silent_speech_amd import TextTransform
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
     from silent_speech_amd.tables import NgramCounts
     a2 = copy.copy(args)
     a2.variant = variant
@@ -172,47 +256,39 @@ def secondary_variant(args, variant, words, corpus, tgd, tld, targets):
     dec = NSDecoder(DeviceTables.from_words(words, lm), args.beam, args.tmax, variant=variant, lm_weight=args.beta,
                     oov_penalty=args.gamma, word_bonus=args.kappa)
     ws = dec.workspace(args.utts)
-    sm = np.zeros(max(args.tmax, 1), np.float32)
-    durs = []
     reps = max(3, args.steps // 4)
     for _ in range(2):
         dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0, ws=ws)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(reps):
-        timed = (k % args.event_every == 0)
-        dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0, ws=ws,
-                                step_ms=sm if timed else None)
-        if timed:
-            durs.append(sm[:ws.steps_run].copy())
+    for _ in range(reps):
+        dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0, ws=ws)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ids_np, lens_np = ws.out_ids[:args.utts].cpu().numpy(), ws.out_len[:args.utts].cpu().numpy()
-    texts = [ids_to_text(TextTransform, ids_np[u, :lens_np[u]].tolist()) for u in range(args.utts)]
-    chars = sum(len(t) for t in texts)
-    T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, a2)
+    nchar, exact, starts = decoded_text_stats(ws.out_ids[:args.utts].cpu().numpy(),
+                                              ws.out_len[:args.utts].cpu().numpy(), tg, tl)
+    chars = int(nchar.sum())
     steps_run = ws.steps_run
-    bytes_per_launch = float(per_step[:steps_run].sum()) / max(steps_run, 1)
-    d = np.concatenate(durs).astype(np.float64) * 1e-3
-    ach = bytes_per_launch / float(d.mean()) / 1e9
+    d = timed_launches(dec, ws, tgd, tld, a2, 2)
+    T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, a2)
+    r = roofline_of(per_step, live, cands, d, steps_run)
     return {"source": VARIANT_SRC[variant], "value": chars * reps / dt, "unit": "chars/s", "decodes": reps,
             "ms_per_decode": 1e3 * dt / reps, "chars_per_decode": chars,
-            "targets_recovered_exactly": sum(int(a == b) for a, b in zip(texts, targets)),
-            "roofline": {"achieved": ach, "frac": ach / HBM_PEAK_GBPS, "unit": "GB/s",
-                         "avg_launch_us": float(d.mean()) * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch}}
+            "targets_recovered_exactly": int(exact.sum()),
+            "target_chars_per_s": float(tl[starts].sum()) * reps / dt,
+            "roofline": {k: r[k] for k in ("achieved", "frac", "unit", "avg_launch_us",
+                                           "algorithmic_bytes_per_launch")}}
 
 
-def default_workload(a) -> bool:
-    return (a.utts == 4096 and a.beam == 16 and a.tmax == 64 and a.variant == "I" and a.order == 5
-            and a.lex_words == 200 and not a.open_lexicon and a.margin == 60.0 and a.beta == 0.05)
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--utts", type=int, default=4096, help="utterances per GPU")
+    ap.add_argument("--utts", type=int, default=4096, help="utterances per GPU (weak scaling)")
+    ap.add_argument("--utts-total", type=int, default=0,
+                    help="split this many utterances over the ranks instead (strong scaling; the 1M-utterance "
+                         "configuration is --utts-total 1000000)")
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--tmax", type=int, default=64)
     ap.add_argument("--variant", default="I", choices=["U", "I", "E"])
@@ -228,7 +304,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20260403)
     ap.add_argument("--check-every", type=int, default=0,
                     help="poll the done counter every this many steps (0 = enqueue all T_max steps)")
-    ap.add_argument("--event-every", type=int, default=4, help="time the nsd_step launches of every n-th decode")
+    ap.add_argument("--timed-decodes", type=int, default=4,
+                    help="decodes after the throughput loop whose nsd_step launches carry HIP events")
     ap.add_argument("--cpu-utts", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--cpu-seconds-all", type=float, default=8.0,
@@ -238,15 +315,40 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse "
                                                              "several ranks on one GPU")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure throughput run)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="seconds after which the self-started ranks of --gpus N are ended")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: start the ranks ourselves, before anything here touches a GPU
+        from silent_speech_amd.launch import spawn_ranks
+        rc = spawn_ranks([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus,
+                         timeout=args.launch_timeout)
+        raise SystemExit(rc)
+    worker(args)
+
+
+def worker(args):
+    global np, torch
+    import numpy as _np
+    import torch as _torch
+    np, torch = _np, _torch
+    # only the JSON line may reach stdout: libraries that print there (gloo's connection notes) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("NSD_BENCH_WATCHDOG"):        # diagnostic: periodic stack dumps of a run that seems stuck
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["NSD_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
@@ -262,15 +364,21 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.dist_backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group reports {dist.get_world_size()} ranks, expected {world}")
 
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
-    from silent_speech_amd.dist import gather_results, last_gathered, unpack_gathered
-    from silent_speech_amd import lib as nsd_lib
+    from silent_speech_amd.dist import gather_results, last_gathered, shard_range, unpack_gathered
     from silent_speech_amd.tables import NgramCounts
 
     if args.open_lexicon and args.lex_words == 200:
         args.lex_words = 100000
-    args.utt0 = rank * args.utts
+    strong = args.utts_total > 0
+    if strong:
+        lo, hi = shard_range(args.utts_total, rank, world)
+        args.utts, args.utt0, n_total = hi - lo, lo, args.utts_total
+    else:
+        args.utt0, n_total = rank * args.utts, args.utts * world
     words, corpus, targets, tg, tl = build_workload(args.utts, args.utt0, args.lex_words, args.corpus,
                                                     args.order, args.open_lexicon)
     lm = NgramCounts(args.order, floor_vsz=(args.variant == "U")).fit(corpus)
@@ -279,20 +387,11 @@ def main():
                     oov_penalty=args.gamma, word_bonus=args.kappa)
     tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
     ws = dec.workspace(args.utts)
-    n_total = args.utts * world
 
-    use_events = not args.no_events
-    step_ms = np.zeros(max(args.tmax, 1), np.float32)
-    durs = []                                   # per-launch nsd_step durations (ms) from HIP events
-
-    def one_decode(timed: bool, k: int = 0):
-        # the whole step loop is enqueued by native code; on every `event_every`-th timed decode each
-        # nsd_step launch is bracketed by HIP events on the launch stream
-        sm = step_ms if (timed and use_events and k % args.event_every == 0) else None
+    def one_decode():
+        # the whole step loop is enqueued by native code
         ids, lens, _ = dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0,
-                                               check_every=args.check_every, ws=ws, step_ms=sm)
-        if sm is not None:
-            durs.append(sm[:ws.steps_run].copy())
+                                               check_every=args.check_every, ws=ws)
         # the exchange runs on every decode; rank 0 turns the receive buffer into (ids, lens) once, after the loop
         gather_results(ids, lens, n_total, dst=0, unpack=False)
 
@@ -302,17 +401,20 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_decode(False)
+        one_decode()
     fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_decode(True, k)
+    for _ in range(args.steps):
+        one_decode()
     fence()
     dt = time.perf_counter() - t0
+    steps_run = ws.steps_run
     if world > 1 and rank == 0:
         # the gathered block of rank 0 must be its own result
-        per, width = args.utts, ws.out_ids.shape[1]
+        per, width = (n_total + world - 1) // world, ws.out_ids.shape[1]
         g_ids, g_len = unpack_gathered(last_gathered(per, width, world, dev), n_total, width)
+        if g_ids.shape[0] != n_total:
+            raise RuntimeError(f"gathered {g_ids.shape[0]} utterances, expected {n_total}")
         if not (torch.equal(g_ids[:args.utts], ws.out_ids[:args.utts])
                 and torch.equal(g_len[:args.utts], ws.out_len[:args.utts].to(g_len.dtype))):
             raise RuntimeError("gathered results differ from rank 0's own decode")
@@ -325,84 +427,81 @@ def main():
     # characters decoded by this rank (identical every repetition: the decode is deterministic)
     dec.raise_on_topk_error(ws)
     ids_np, lens_np = ws.out_ids[:args.utts].cpu().numpy(), ws.out_len[:args.utts].cpu().numpy()
-    from silent_speech_amd.decoder import ids_to_text
-    from silent_speech_amd import TextTransform
-    texts = [ids_to_text(TextTransform, ids_np[u, :lens_np[u]].tolist()) for u in range(args.utts)]
-    chars = torch.tensor([sum(len(s) for s in texts)], dtype=torch.float64, device=rdev)
-    exact = torch.tensor([sum(int(a == b) for a, b in zip(texts, targets))], dtype=torch.float64, device=rdev)
+    nchar, exact, starts = decoded_text_stats(ids_np, lens_np, tg, tl)
+    sums = torch.tensor([float(nchar.sum()), float(exact.sum()), float(starts.sum()), float(tl[starts].sum()),
+                         float(args.utts)], dtype=torch.float64, device=rdev)
+    per_rank = torch.zeros(world, dtype=torch.float64, device=rdev)
+    per_rank[rank] = float(args.utts)
     if world > 1:
-        dist.all_reduce(chars)
-        dist.all_reduce(exact)
+        dist.all_reduce(sums)
+        dist.all_reduce(per_rank)
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
+    chars, n_exact, n_starts, target_chars, n_decoded = (float(x) for x in sums.tolist())
+    if int(n_decoded) != n_total:
+        raise RuntimeError(f"ranks decoded {int(n_decoded)} utterances in all, expected {n_total}")
 
+    shape = (f"{n_total} utterances split over {world} GPU(s)" if strong else f"{args.utts} utterances per GPU")
     result = {
         "metric": "NS-decoded chars/sec (beam 16, trie+5-gram)" if (args.beam == 16 and args.order == 5)
                   else f"NS-decoded chars/sec (beam {args.beam}, trie+{args.order}-gram)",
-        "value": float(chars.item()) * args.steps / dt,
+        "value": chars * args.steps / dt,
         "unit": "chars/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": ("configs[2]: open 100k-word lexicon" if args.open_lexicon else
-                                "configs[1]: closed 200-word template lexicon") +
-                               f", {args.utts} utterances per GPU, beam {args.beam}, char {args.order}-gram, "
+        "config": {"workload": ("configs[2]: open 100k-word lexicon (random-access stress: random words, most "
+                                "n-grams unseen)" if args.open_lexicon else
+                                ("configs[4]: " if strong and n_total >= 1000000 else "configs[1]: ") +
+                                "closed 200-word template lexicon") +
+                               f", {shape}, beam {args.beam}, char {args.order}-gram, "
                                f"variant {args.variant} ({VARIANT_SRC[args.variant]}), beta {args.beta}, gamma {args.gamma}, "
                                f"margin {args.margin}, T_max {args.tmax}",
-                   "utterances_total": n_total, "parallelism": f"utterance-sharded x{world}, replicated tables",
-                   "chars_per_decode": float(chars.item()),
-                   "targets_recovered_exactly": int(exact.item()),
-                   "scorer_launches_per_decode": ws.steps_run},
+                   "utterances_total": n_total, "utterances_per_rank": [int(x) for x in per_rank.tolist()],
+                   "ranks_reported_by_process_group": dist.get_world_size() if world > 1 else 1,
+                   "parallelism": f"utterance-sharded x{world}, replicated tables",
+                   "chars_per_decode": chars,
+                   "targets_recovered_exactly": int(n_exact),
+                   "targets_recovered_as_prefix": int(n_starts),
+                   "target_chars_per_decode": target_chars,
+                   "scorer_launches_per_decode": steps_run},
+        # characters of planted targets that came back (the decoded text starts with the target; the copy of the
+        # decoder without an EOS option keeps decoding flat logits after the target's end)
+        "target_chars_per_s": target_chars * args.steps / dt,
     }
 
-    # roofline of the dominant kernel (nsd_step): algorithmic bytes / measured launch duration
-    T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, args)
-    if len(per_step) < ws.steps_run:            # launches after every utterance finished move no bytes
-        pad = ws.steps_run - len(per_step)
-        per_step = np.concatenate([per_step, np.zeros(pad, np.int64)])
-        live = np.concatenate([live, np.zeros(pad, np.int64)])
-        cands = np.concatenate([cands, np.zeros(pad, np.int64)])
-    bytes_per_launch = float(per_step[:ws.steps_run].sum()) / max(ws.steps_run, 1)
-    if use_events and durs:
-        d = np.concatenate(durs).astype(np.float64) * 1e-3                 # seconds
-        avg = float(d.mean())
-        achieved = bytes_per_launch / avg / 1e9
-        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                              "kernel": "nsd_step_kernel", "launches_timed": int(d.size),
-                              "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
-                              "mean_live_hyps_per_launch": float(live.sum() / max(ws.steps_run, 1)),
-                              "mean_children_per_live_hyp": float(cands.sum() / max(live.sum(), 1)),
-                              "busiest_launch": {"us": float(d.reshape(len(durs), -1).mean(0).max() * 1e6),
-                                                 "GBps": float((per_step[:ws.steps_run] /
-                                                                np.maximum(d.reshape(len(durs), -1).mean(0)[:len(per_step[:ws.steps_run])], 1e-9)).max() / 1e9)}}
-    if "roofline" in result and default_workload(args):
-        # HBM bytes per nsd_step launch from separate rocprofv3 --pmc passes of this same command
-        # (profiles/r01_pmc_traffic.json, written by scripts/collect_traffic.py): 2 x FETCH_SIZE + WRITE_SIZE
-        try:
-            tr = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            result["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        except Exception:
-            pass
+    # roofline of the dominant kernel (nsd_step): algorithmic bytes / launch duration from HIP events, measured
+    # on decodes of their own after the throughput window
+    if not args.no_events and args.timed_decodes > 0:
+        d = timed_launches(dec, ws, tgd, tld, args, args.timed_decodes)
+        T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, args)
+        result["roofline"] = roofline_of(per_step, live, cands, d, steps_run)
+        result["roofline"]["traffic_note"] = ("HBM-side bytes need separate rocprofv3 --pmc passes and are not "
+                                              "measured in this run; see profiles/ for the passes taken on this "
+                                              "command")
     if args.also and args.also != args.variant and world == 1:
-        result["variant_" + args.also] = secondary_variant(args, args.also, words, corpus, tgd, tld, targets)
+        result["variant_" + args.also] = secondary_variant(args, args.also, words, corpus, tgd, tld, tg, tl)
     if not args.no_cpu and world == 1:
+        from silent_speech_amd.decoder import ids_to_text
+        from silent_speech_amd import TextTransform
+        n_cmp = min(args.cpu_utts, args.utts)
+        texts = [ids_to_text(TextTransform, ids_np[u, :lens_np[u]].tolist()) for u in range(n_cmp)]
         result["cpu_baseline"] = cpu_baseline(words, corpus, targets, args, texts)
         result["cpu_baseline"]["host_cpus"] = os.cpu_count()
         if args.cpu_seconds_all > 0:
             result["cpu_baseline"]["all_cores"] = cpu_all_cores(words, corpus, targets, args)
         result["speedup_vs_cpu_1core"] = result["value"] / result["cpu_baseline"]["value"]
-    print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

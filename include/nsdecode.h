@@ -9,7 +9,10 @@
  * Conventions
  *   - every pointer marked "device" is caller-owned HIP device memory
  *     (e.g. torch.Tensor.data_ptr()); the library allocates device memory
- *     only inside nsd_tables_create and frees it in nsd_tables_destroy;
+ *     only inside nsd_tables_create and frees it in nsd_tables_destroy.
+ *     One exception, host side only: nsd_decode_synth called with step_ms or
+ *     check_every > 0 keeps a pool of HIP events per device and one pinned
+ *     host word between calls; nsd_shutdown() releases them;
  *   - kernels are enqueued on the caller's stream and never synchronise;
  *   - return value: 0 = NSD_OK, < 0 = argument error (NSD_E_*), > 0 = a
  *     hipError_t value; nsd_strerror() describes all three;
@@ -175,13 +178,19 @@ typedef struct NsdBeamState {
     uint32_t *node;      /* device [N*B] trie node of the current word prefix, or NSD_NODE_DEAD */
     uint32_t *meta;      /* device [N*B] flags | generated length << 8 */
     uint32_t *utt;       /* device [N]   see NSD_U_* */
-    uint32_t *done_count;/* device [1]   number of utterances that reached NSD_U_DONE */
+    uint32_t *done_count;/* device [1]   number of utterances that reached NSD_U_DONE; a step adds the
+                                         utterances that finish in it to the word of its `out` state, so two
+                                         states used as a ping-pong pair must share this one word */
 } NsdBeamState;
 
 /* ---- entry points ---------------------------------------------------- */
 
 int nsd_version(void);
 const char *nsd_strerror(int code);
+
+/* Release what nsd_decode_synth keeps between calls (HIP events, one pinned host word).  Optional; nothing
+ * else in the library holds state outside NsdTables.  Not to be called while a decode is running. */
+int nsd_shutdown(void);
 
 /* hash used for both tables (exported so that table builders can be checked) */
 uint64_t nsd_hash64(uint64_t key);

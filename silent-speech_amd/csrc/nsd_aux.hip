@@ -618,21 +618,39 @@ int nsd_step_with_events(const NsdTables *t, const NsdParams *p, const float *lo
                          int32_t N, int32_t B, int32_t V, void *stream, hipEvent_t ev0, hipEvent_t ev1);   // nsd_step.hip
 
 namespace {
+constexpr int MAX_DEVICES = 64;
 std::mutex g_ev_mutex;
-std::vector<hipEvent_t> g_events;          // grown on demand, reused by every timed decode
-uint32_t *g_host_done = nullptr;           // pinned word for the done-counter poll
+std::vector<hipEvent_t> g_events[MAX_DEVICES];   // per device: grown on demand, reused by every timed decode
+uint32_t *g_host_done = nullptr;                 // pinned word for the done-counter poll
 
-int ensure_events(size_t n)
+int ensure_events(int dev, size_t n)
 {
-    while (g_events.size() < n) {
+    std::vector<hipEvent_t> &ev = g_events[dev];
+    while (ev.size() < n) {
         hipEvent_t e;
         hipError_t err = hipEventCreate(&e);
         if (err != hipSuccess) return (int)err;
-        g_events.push_back(e);
+        ev.push_back(e);
     }
     return 0;
 }
 } // namespace
+
+extern "C" int nsd_shutdown(void)
+{
+    std::lock_guard<std::mutex> lock(g_ev_mutex);
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        if (g_events[d].empty()) continue;
+        if (hipSetDevice(d) == hipSuccess)
+            for (hipEvent_t e : g_events[d]) (void)hipEventDestroy(e);
+        g_events[d].clear();
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    if (g_host_done) { (void)hipHostFree(g_host_done); g_host_done = nullptr; }
+    return NSD_OK;
+}
 
 extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const NsdBeamState *st,
                                 uint64_t base_seed, int64_t utt0,
@@ -649,13 +667,19 @@ extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const Ns
     hipStream_t s = (hipStream_t)stream;
     const size_t NB = (size_t)N * B;
     std::unique_lock<std::mutex> lock(g_ev_mutex, std::defer_lock);
+    hipEvent_t *ev = nullptr;
     if (step_ms || check_every > 0) lock.lock();
     if (step_ms) {
-        if ((rc = ensure_events(2 * (size_t)T)) != 0) return rc;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= MAX_DEVICES) return NSD_E_SIZE;
+        if ((rc = ensure_events(dev, 2 * (size_t)T)) != 0) return rc;
+        ev = g_events[dev].data();
         for (int i = 0; i < T; ++i) step_ms[i] = -1.0f;
     }
     if (check_every > 0 && !g_host_done) {
-        hipError_t e = hipHostMalloc((void **)&g_host_done, sizeof(uint32_t), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&g_host_done, sizeof(uint32_t), hipHostMallocPortable);
         if (e != hipSuccess) return (int)e;
     }
     int ran = 0;
@@ -663,8 +687,8 @@ extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const Ns
         rc = nsd_synth_logits(st, base_seed, utt0, targets, target_len, stride, margin, logits, N, B, stream);
         if (rc != 0) return rc;
         rc = nsd_step_with_events(t, p, logits, st, st, backptr + (size_t)step * NB, token + (size_t)step * NB,
-                                  nullptr, N, B, NSD_V, stream, step_ms ? g_events[2 * step] : nullptr,
-                                  step_ms ? g_events[2 * step + 1] : nullptr);
+                                  nullptr, N, B, NSD_V, stream, ev ? ev[2 * step] : nullptr,
+                                  ev ? ev[2 * step + 1] : nullptr);
         if (rc != 0) return rc;
         ran = step + 1;
         if (check_every > 0 && ran % check_every == 0 && ran < T) {
@@ -682,7 +706,7 @@ extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const Ns
         if (e != hipSuccess) return (int)e;
         for (int i = 0; i < ran; ++i) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]) == hipSuccess) step_ms[i] = ms;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) step_ms[i] = ms;
         }
     }
     return NSD_OK;

@@ -902,9 +902,11 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
 {
     constexpr int UPW = 64 / G;
     const uint32_t lds_per_wave = a.lds_per_utt * UPW;
-    // waves per workgroup: the count (4, 2 or 1) that lets most waves share a CU's 160 KiB of LDS
-    int waves = 4, best = 0;
+    // waves per workgroup: the count (4, 2 or 1) that lets most waves share a CU's 160 KiB of LDS, among
+    // those whose workgroup stays within the 64 KiB of dynamic LDS a launch may ask for without opting in
+    int waves = 1, best = 0;
     for (int w = 4; w >= 1; w >>= 1) {
+        if (lds_per_wave * (uint32_t)w > 65536u) continue;
         const int per_cu = (int)(163840u / (lds_per_wave * (uint32_t)w)) * w;
         if (per_cu > best) { best = per_cu; waves = w; }
     }

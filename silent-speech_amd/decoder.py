@@ -159,8 +159,10 @@ class NSDecoder:
                    "nsd_state_init")
         ws.steps_run = 0
 
-    def step(self, ws: Workspace, logits: Optional[torch.Tensor] = None) -> None:
-        """One scorer launch on step index ws.steps_run."""
+    def step(self, ws: Workspace, logits: Optional[torch.Tensor] = None,
+             mask_out: Optional[torch.Tensor] = None) -> None:
+        """One scorer launch on step index ws.steps_run.  ``mask_out`` (int64 [N*B], device) receives the lexicon
+        masks of this step's live hypotheses instead of the workspace's per-step mask array."""
         t = ws.steps_run
         if t >= ws.T:
             raise ValueError("all max_new_tokens steps already ran")
@@ -170,6 +172,11 @@ class NSDecoder:
             raise ValueError("logits must be a contiguous float32 [N*B, 40] tensor on the decoder's device")
         NB = max(ws.N * ws.B, 1)
         mask_ptr = ws.masks.data_ptr() + t * NB * 8 if ws.masks is not None else None
+        if mask_out is not None:
+            if mask_out.dtype != torch.int64 or mask_out.numel() < NB or not mask_out.is_contiguous() \
+                    or mask_out.device != ws.score.device:
+                raise ValueError("mask_out must be a contiguous int64 tensor of N*B elements on the decoder's device")
+            mask_ptr = mask_out.data_ptr()
         _lib.check(self.L.nsd_step(self.tables.handle, C.byref(self.params), lg.data_ptr(),
                                    C.byref(ws.ptrs), C.byref(ws.ptrs),
                                    ws.backptr.data_ptr() + t * NB, ws.token.data_ptr() + t * NB, mask_ptr,

@@ -55,7 +55,8 @@ class BeamStatePtrs(C.Structure):
 EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "nsd_tables_destroy",
            "nsd_tables_order", "nsd_state_init", "nsd_step", "nsd_backtrace", "nsd_gather_ids",
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
-           "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad", "nsd_kv_reorder"]
+           "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad", "nsd_kv_reorder",
+           "nsd_shutdown"]
 
 _lib = None
 

@@ -38,13 +38,41 @@ def make_sentences(words: list[str], n: int, seed: int, min_words: int = 3, max_
     return out
 
 
+TARGET_BLOCK = 4096
+
+
+def targets_for_range(words: list[str], lo: int, hi: int, min_words: int = 3, max_words: int = 7) -> list[str]:
+    """Planted target sentences of the utterances [lo, hi) of the global numbering.
+
+    Utterances are drawn in blocks of TARGET_BLOCK with one seed per block (1000 + block number), so the
+    target of utterance u does not depend on how the utterances are split over ranks."""
+    out: list[str] = []
+    if hi <= lo:
+        return out
+    for k in range(lo // TARGET_BLOCK, (hi - 1) // TARGET_BLOCK + 1):
+        b0 = k * TARGET_BLOCK
+        block = make_sentences(words, TARGET_BLOCK, 1000 + k, min_words, max_words)
+        out.extend(block[max(lo, b0) - b0:min(hi, b0 + TARGET_BLOCK) - b0])
+    return out
+
+
+_TOKEN_OF_BYTE = np.full(256, -1, np.int16)
+for _i, _c in enumerate(BASE_CHARS):
+    _TOKEN_OF_BYTE[ord(_c)] = _i
+
+
 def pack_targets(targets: list[str]):
     """(int8 [N, S] token ids, int32 [N] lengths) of planted target strings."""
-    S = max(1, max((len(t) for t in targets), default=1))
-    tg = np.zeros((len(targets), S), np.int8)
-    tl = np.zeros(len(targets), np.int32)
-    for i, t in enumerate(targets):
-        ids = [BASE_CHARS.index(c) for c in t]
-        tg[i, :len(ids)] = ids
-        tl[i] = len(ids)
+    n = len(targets)
+    tl = np.fromiter((len(t) for t in targets), np.int32, count=n)
+    S = max(1, int(tl.max()) if n else 1)
+    tg = np.zeros((n, S), np.int8)
+    if n and int(tl.sum()):
+        flat = _TOKEN_OF_BYTE[np.frombuffer("".join(targets).encode("ascii"), np.uint8)]
+        if (flat < 0).any():
+            raise ValueError("target outside the base characters")
+        rows = np.repeat(np.arange(n), tl)
+        starts = np.cumsum(tl) - tl
+        cols = np.arange(flat.shape[0]) - np.repeat(starts, tl)
+        tg[rows, cols] = flat.astype(np.int8)
     return tg, tl

@@ -714,6 +714,9 @@ def test_step_into_a_second_state_buffer_equals_in_place():
 
     L = lib.load()
     w = [Workspace(N, B, T, dev), Workspace(N, B, T, dev)]
+    # a ping-pong pair shares one done counter (every step adds to the word of its output state)
+    w[1].done_count = w[0].done_count
+    w[1].ptrs.done_count = w[0].done_count.data_ptr()
     dec.init(w[0])
     st = torch.cuda.current_stream().cuda_stream
     for t in range(T):
@@ -735,3 +738,20 @@ def test_step_into_a_second_state_buffer_equals_in_place():
     assert (out_ids.cpu().numpy() == ids_a).all()
     assert (out_sc.cpu().numpy().view(np.int64) == sc_a.view(np.int64)).all()
     assert bool((last.utt[:N] & lib.U_DONE).all())              # every utterance finished well before step 40
+    assert int(w[0].done_count.item()) == N
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beam,lanes,n_utts", [(60, 0, 48), (28, 32, 96), (15, 16, 128)])
+def test_largest_lds_footprints_of_the_length_normalised_copy(dev, beam, lanes, n_utts):
+    """Beams just below a lane-group width with the copy of the decoder that also keeps raw scores in LDS
+    (eval_ar.py): the largest per-workgroup LDS footprints the launcher can ask for."""
+    case = dict(variant="E", beam=beam, lm_order=3, beta=0.1, margin=6.0, gamma=1.0, kappa=0.35, alpha=0.6,
+                min_len_for_eos=4, max_new_tokens=20, n_words=300, lex_seed=5, max_len=6, n_corpus=2000, corpus_seed=6,
+                n_utts=n_utts, target_seed=7, base_seed=1234, min_words=2, max_words=4, lanes=lanes,
+                name=f"lds_E_{beam}_{lanes}")
+    # a plain lexicon never empties a hypothesis' options, so the top-k fall-back (which raises for a beam wider
+    # than the vocabulary in this copy) is not reached
+    ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)
+    assert err is None
+    _compare_with_trace(ws, ids, lens, scores, ref, case["name"])
