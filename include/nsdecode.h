@@ -52,6 +52,7 @@ extern "C" {
 #define NSD_E_TABLE        -5   /* malformed table (capacity not a power of two, empty trie, ...) */
 #define NSD_E_VARIANT      -6
 #define NSD_E_SIZE         -7   /* negative / oversized count */
+#define NSD_E_NOALLOC_SIZE -8   /* batch larger than the built-in scratch of nsd_decode_synth_noalloc */
 
 /* beam flags (low byte of NsdBeamState.meta) */
 #define NSD_F_FINISHED      1u  /* last token is EOS */
@@ -344,6 +345,24 @@ int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const NsdBeamState 
                      int32_t T, int32_t N, int32_t B,
                      uint8_t *out_ids, int32_t *out_len, double *out_score,
                      int32_t check_every, float *step_ms, int32_t *steps_run, void *stream);
+
+/* nsd_decode_synth for callers that cannot allocate or hand over workspaces (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same decode, same results as nsd_decode_synth with check_every = 0 and no step_ms, but the beam state, the
+ * logits rows and the back-pointer / token arrays live in a scratch array built into the library
+ * (NSD_NOALLOC_SCRATCH_BYTES of device memory on every GPU the library runs on, held until the process ends);
+ * the caller passes only the inputs (tables, parameters, targets) and the outputs.  The call allocates
+ * nothing and does not synchronise.
+ *   limits   N * B <= NSD_NOALLOC_MAX_HYPS and N * B * T <= NSD_NOALLOC_MAX_CELLS, else NSD_E_NOALLOC_SIZE
+ *   sharing  all calls on one GPU use that GPU's one array: calls that overlap on a GPU (two streams, two
+ *            threads) race; calls on one stream, or ordered by events, are fine */
+#define NSD_NOALLOC_MAX_HYPS      65536u                  /* e.g. 4096 utterances x beam 16 */
+#define NSD_NOALLOC_MAX_CELLS     (65536u * 64u)          /* ... x 64 steps */
+#define NSD_NOALLOC_SCRATCH_BYTES (22u * 1024u * 1024u)
+int nsd_decode_synth_noalloc(const NsdTables *t, const NsdParams *p, uint64_t base_seed, int64_t utt0,
+                             const int8_t *targets, const int32_t *target_len, int32_t stride, float margin,
+                             int32_t T, int32_t N, int32_t B,
+                             uint8_t *out_ids, int32_t *out_len, double *out_score, void *stream);
 
 #ifdef __cplusplus
 }

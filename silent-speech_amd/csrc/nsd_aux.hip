@@ -22,6 +22,8 @@ extern "C" const char *nsd_strerror(int code)
     case NSD_E_TABLE:   return "malformed table";
     case NSD_E_VARIANT: return "unknown decoder variant";
     case NSD_E_SIZE:    return "size argument out of range";
+    case NSD_E_NOALLOC_SIZE: return "batch exceeds the built-in scratch of nsd_decode_synth_noalloc "
+                                    "(N*B <= 65536 and N*B*T <= 4194304)";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -710,4 +712,91 @@ extern "C" int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const Ns
         }
     }
     return NSD_OK;
+}
+
+// ---------------------------------------------------------------------
+// nsd_decode_synth without any allocation: the beam state, the logits rows and the back-pointer / token
+// arrays live in one file-scope device array instead of caller-owned workspaces.  Every GPU the library runs
+// on holds its own copy of the array until the process ends; its address on a device is looked up once, with
+// that device current, and from then on only that address is handed to kernels.
+// ---------------------------------------------------------------------
+namespace {
+constexpr size_t NA_HYPS = NSD_NOALLOC_MAX_HYPS;                   // N * B
+constexpr size_t NA_CELLS = NSD_NOALLOC_MAX_CELLS;                 // N * B * T
+constexpr size_t na_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// offsets of the parts (all multiples of 256 bytes)
+constexpr size_t NA_SCORE = 0;
+constexpr size_t NA_LMSUM = NA_SCORE + na_align(8 * NA_HYPS);
+constexpr size_t NA_LMSUM_E = NA_LMSUM + na_align(8 * NA_HYPS);
+constexpr size_t NA_CTX = NA_LMSUM_E + na_align(8 * NA_HYPS);
+constexpr size_t NA_HIST = NA_CTX + na_align(8 * NA_HYPS);
+constexpr size_t NA_CTX_ID = NA_HIST + na_align(8 * NA_HYPS);
+constexpr size_t NA_CTXE_ID = NA_CTX_ID + na_align(4 * NA_HYPS);
+constexpr size_t NA_NODE = NA_CTXE_ID + na_align(4 * NA_HYPS);
+constexpr size_t NA_META = NA_NODE + na_align(4 * NA_HYPS);
+constexpr size_t NA_UTT = NA_META + na_align(4 * NA_HYPS);         // N <= N * B
+constexpr size_t NA_DONE = NA_UTT + na_align(4 * NA_HYPS);
+constexpr size_t NA_LOGITS = NA_DONE + 256;
+constexpr size_t NA_BACKPTR = NA_LOGITS + na_align(4 * NSD_V * NA_HYPS);
+constexpr size_t NA_TOKEN = NA_BACKPTR + na_align(NA_CELLS);
+constexpr size_t NA_BYTES = NA_TOKEN + na_align(NA_CELLS);
+static_assert(NA_BYTES <= (size_t)NSD_NOALLOC_SCRATCH_BYTES, "nsdecode.h states a smaller scratch size than the layout needs");
+
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[MAX_DEVICES];                         // device address of `scratch` on each device
+}
+
+static __device__ __align__(256) unsigned char scratch[NSD_NOALLOC_SCRATCH_BYTES];
+
+// device address of the scratch array on the current device (looked up on the first call per device)
+static int nsd_scratch_address(unsigned char **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return NSD_E_SIZE;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!ptr) return NSD_E_NULL;
+        g_scratch_ptr[dev] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return NSD_OK;
+}
+
+extern "C" int nsd_decode_synth_noalloc(const NsdTables *t, const NsdParams *p, uint64_t base_seed, int64_t utt0,
+                                        const int8_t *targets, const int32_t *target_len, int32_t stride,
+                                        float margin, int32_t T, int32_t N, int32_t B,
+                                        uint8_t *out_ids, int32_t *out_len, double *out_score, void *stream)
+{
+    if (!t || !p) return NSD_E_NULL;
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (T < 0 || T > NSD_MAX_STEPS || N < 0 || stride < 0) return NSD_E_SIZE;
+    if ((size_t)N * (size_t)B > NA_HYPS || (size_t)N * (size_t)B * (size_t)T > NA_CELLS) return NSD_E_NOALLOC_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!targets || !target_len || !out_ids || !out_len) return NSD_E_NULL;
+    unsigned char *base = nullptr;
+    int rc = nsd_scratch_address(&base);
+    if (rc != 0) return rc;
+    NsdBeamState st;
+    st.score = reinterpret_cast<double *>(base + NA_SCORE);
+    st.lmsum = reinterpret_cast<double *>(base + NA_LMSUM);
+    st.lmsum_e = reinterpret_cast<double *>(base + NA_LMSUM_E);
+    st.ctx = reinterpret_cast<uint64_t *>(base + NA_CTX);
+    st.hist = reinterpret_cast<uint64_t *>(base + NA_HIST);
+    st.ctx_id = reinterpret_cast<uint32_t *>(base + NA_CTX_ID);
+    st.ctxe_id = reinterpret_cast<uint32_t *>(base + NA_CTXE_ID);
+    st.node = reinterpret_cast<uint32_t *>(base + NA_NODE);
+    st.meta = reinterpret_cast<uint32_t *>(base + NA_META);
+    st.utt = reinterpret_cast<uint32_t *>(base + NA_UTT);
+    st.done_count = reinterpret_cast<uint32_t *>(base + NA_DONE);
+    // The array keeps what the last call left.  nsd_state_init rewrites the first hypothesis of every
+    // utterance, the utterance words and the done counter; every other hypothesis slot, logits row and
+    // back-pointer cell is written by the step that first makes it valid before anything reads it.
+    return nsd_decode_synth(t, p, &st, base_seed, utt0, targets, target_len, stride, margin,
+                            reinterpret_cast<float *>(base + NA_LOGITS), base + NA_BACKPTR, base + NA_TOKEN,
+                            T, N, B, out_ids, out_len, out_score, 0, nullptr, nullptr, stream);
 }

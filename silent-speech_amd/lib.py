@@ -56,7 +56,7 @@ EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "ns
            "nsd_tables_order", "nsd_state_init", "nsd_step", "nsd_backtrace", "nsd_gather_ids",
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
            "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad", "nsd_kv_reorder",
-           "nsd_shutdown"]
+           "nsd_shutdown", "nsd_decode_synth_noalloc"]
 
 _lib = None
 
@@ -91,6 +91,8 @@ def load():
     L.nsd_synth_logits.argtypes = [C.POINTER(BeamStatePtrs), u64, i64, vp, vp, i32, C.c_float, vp, i32, i32, vp]
     L.nsd_decode_synth.argtypes = [vp, C.POINTER(Params), C.POINTER(BeamStatePtrs), u64, i64, vp, vp, i32, C.c_float,
                                    vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.nsd_decode_synth_noalloc.argtypes = [vp, C.POINTER(Params), u64, i64, vp, vp, i32, C.c_float, i32, i32, i32,
+                                           vp, vp, vp, vp]
     L.nsd_rerank_lm.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
     L.nsd_kv_reorder.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.nsd_cond_dist.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
