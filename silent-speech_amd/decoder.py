@@ -21,7 +21,7 @@ from .text import finish_transcripts, ids_to_text  # noqa: F401  (ids_to_text: s
 from .tables import (BASE_CHARS, BOS_ID, EOS_ID, PAD_ID, VOCAB, HostTrie, NgramTables, compile_ngram,
                      flatten_trie)
 
-__all__ = ["DeviceTables", "NSDecoder", "Workspace", "constrained_beam_decode", "ids_to_text",
+__all__ = ["DeviceTables", "NSDecoder", "Workspace", "constrained_beam_decode", "ids_to_text", "clear_table_cache",
            "ctc_greedy_batch", "lm_logp_batch", "rerank_gather_batch", "log_softmax_rows", "rerank_lm_batch"]
 
 
@@ -273,8 +273,22 @@ class NSDecoder:
 _TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
+def _fingerprint(trie, lm) -> tuple:
+    """Cheap signature of the objects' contents, so that an `lm.fit(...)` or `trie.insert(...)` on an object the
+    cache already knows is noticed (an O(1) check, not a proof: `clear_table_cache()` is the sure way)."""
+    t = (len(trie.next), bool(trie.end), tuple(sorted(map(str, trie.next)))[:40])
+    if lm is None:
+        return t, None
+    return t, (int(lm.order), len(lm.counts), len(lm.context), len(lm.V))
+
+
+def clear_table_cache() -> None:
+    """Forget the device tables built for earlier (trie, lm) objects."""
+    _TABLE_CACHE.clear()
+
+
 def _tables_for(trie, lm, floor_vsz) -> DeviceTables:
-    key = (id(trie), id(lm), floor_vsz, torch.cuda.current_device())
+    key = (id(trie), id(lm), floor_vsz, torch.cuda.current_device(), _fingerprint(trie, lm))
     hit = _TABLE_CACHE.get(key)
     if hit is not None and hit[0] is trie and hit[1] is lm:
         _TABLE_CACHE.move_to_end(key)

@@ -19,6 +19,13 @@ def golden():
     return json.loads((ROOT / "tests" / "golden" / "ns_golden.json").read_text(encoding="utf-8"))
 
 
+@pytest.fixture(scope="session")
+def golden_tail():
+    """Recorded from the reference by tests/golden/make_golden_tail.py: scores and near-tie gaps at benchmark
+    sizes, the CTC proposal / rerank statements of both drivers, make_lexicon's filters, load_lexicon."""
+    return json.loads((ROOT / "tests" / "golden" / "ns_golden_tail.json").read_text(encoding="utf-8"))
+
+
 def pytest_collection_modifyitems(config, items):
     # GPU tests must not be silently skipped on the GPU box and must not run on CPU-only hosts.
     try:

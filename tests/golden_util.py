@@ -52,3 +52,45 @@ def decode_kwargs(case):
 
 def enc(ids, code):
     return "".join(code[i] for i in ids[1:])
+
+
+def ctc_frames(seed: int, target: str, Tp: int, noise: float = 0.5, wrong: float = 0.05) -> np.ndarray:
+    """Seeded (Tp, 40) float32 CTC logits with a planted frame path: every target character repeated over 1-3
+    frames, blanks (PAD, id 39) between equal neighbours and here and there, a few BOS/EOS frames and a few
+    wrong characters; the rest of the frames are blanks.  numpy's legacy RandomState keeps this stable."""
+    rs = np.random.RandomState(seed)
+    path = []
+    prev = None
+    for tok in target_tokens(target):
+        if tok == prev or rs.rand() < 0.3:
+            path += [synth.PAD_ID] * int(rs.randint(1, 3))
+        if rs.rand() < wrong:
+            tok_f = int(rs.randint(0, 37))
+        else:
+            tok_f = tok
+        path += [tok_f] * int(rs.randint(1, 4))
+        if rs.rand() < 0.05:
+            path.append(synth.BOS_ID if rs.rand() < 0.5 else synth.EOS_ID)
+        prev = tok
+    path = (path + [synth.PAD_ID] * Tp)[:Tp]
+    x = (rs.standard_normal((Tp, synth.VOCAB)) * noise).astype(np.float32)
+    x[np.arange(Tp), np.array(path)] += np.float32(6.0)
+    return x
+
+
+def corrupt(seed: int, text: str, rate: float = 0.12) -> str:
+    """A transcript with a few wrong, doubled or tripled letters (what an AR hypothesis looks like before the
+    post-correction)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for ch in text:
+        r = rs.rand()
+        if r < rate / 3:
+            out.append(synth.BASE_CHARS[int(rs.randint(0, 26))])
+        elif r < 2 * rate / 3:
+            out += [ch, ch, ch]
+        elif r < rate:
+            continue
+        else:
+            out.append(ch)
+    return "".join(out)

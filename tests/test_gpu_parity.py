@@ -79,6 +79,61 @@ def test_golden_cases_through_the_drop_in(golden, dev):
     assert n > 80
 
 
+def test_golden_cases_through_the_per_file_bindings(golden, dev):
+    """The same recorded runs through the bindings that carry each reference file's own signature, called the
+    way the drivers call them (inference_emg_llm.py:432-435, eval_ar.py:533-545): keyword arguments, no variant
+    switch."""
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.compat import eval_ar, inference_emg_llm, ns_utils
+    mod = {"U": ns_utils, "I": inference_emg_llm, "E": eval_ar}
+    code = golden["meta"]["token_code"]
+    n = 0
+    for case in golden["cases"]:
+        words, trie, lm = case_model(case)
+        for u, rec in enumerate(case["utts"]):
+            useed = synth.utt_seed(case["base_seed"], u)
+            tgt = target_tokens(rec["target"])
+            calls = []
+
+            def step_fn(ids):
+                calls.append(enc(ids, code))
+                return torch.from_numpy(synth.logits_row(useed, ids, tgt, case["margin"])).unsqueeze(0)
+
+            kw = dict(beam=case["beam"], max_new_tokens=case["max_new_tokens"], trie=trie, lm=lm,
+                      lm_weight=case["beta"], oov_penalty=case["gamma"])
+            if case["variant"] == "E":
+                kw.update(word_bonus=case["kappa"], length_penalty_alpha=case["alpha"],
+                          min_len_for_eos=case["min_len_for_eos"])
+            m = mod[case["variant"]]
+            if "raises" in rec:
+                with pytest.raises(RuntimeError):
+                    m.constrained_beam_decode(step_fn, TextTransform, **kw)
+                continue
+            ids = m.constrained_beam_decode(step_fn, TextTransform, **kw)
+            assert calls == rec["calls"], (case["name"], u)
+            assert ids == rec["ids"], (case["name"], u)
+            assert m.ids_to_text(TextTransform, ids) == rec["text"]
+            n += 1
+    assert n > 80
+
+
+def test_drop_in_notices_a_refitted_language_model(dev):
+    """The drop-in caches device tables per (trie, lm) object; refitting the same LM object must not decode with
+    the old tables."""
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.compat import ns_utils
+    words = ["ab", "ba"]
+    trie = O.build_trie(words)
+    lm = O.NgramLM(2).fit(["ab ab ab ab"])
+    flat = lambda ids: torch.zeros(1, 40)                              # noqa: E731
+    a = ns_utils.constrained_beam_decode(flat, TextTransform, 2, 3, trie, lm, lm_weight=5.0, allow_eos_anytime=False)
+    want_a = O.constrained_beam_decode(flat, O.TextTransformLike, 2, 3, trie, lm, lm_weight=5.0, allow_eos_anytime=False)
+    lm.fit(["ba ba ba ba ba ba ba ba ba ba"])
+    b = ns_utils.constrained_beam_decode(flat, TextTransform, 2, 3, trie, lm, lm_weight=5.0, allow_eos_anytime=False)
+    want_b = O.constrained_beam_decode(flat, O.TextTransformLike, 2, 3, trie, lm, lm_weight=5.0, allow_eos_anytime=False)
+    assert a == want_a and b == want_b and want_a != want_b
+
+
 def _run_case_batched(case, dev, with_masks=True):
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
     words = case_words(case)

@@ -71,8 +71,8 @@ def test_postprocess(golden):
 
 
 def test_ctc_collapse_known_answers():
-    # repeats are dropped before specials: a,PAD,a -> "aa" but a,a -> "a"
-    # (inference_emg_llm.py:447-455)
+    # small readable cases next to the recorded reference outputs of tests/test_oracle_golden_tail.py:
+    # repeats are dropped before specials: a,PAD,a -> "aa" but a,a -> "a" (inference_emg_llm.py:447-455)
     TT = O.TextTransformLike
 
     def frames(tokens):

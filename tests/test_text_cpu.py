@@ -17,9 +17,9 @@ def test_postprocess_matches_reference_outputs(golden):
         assert postprocess(s, trie.is_word, words) == want
 
 
-def test_build_lexicon_filters():
-    # parity unpinned: scripts/make_lexicon.py keeps these filters inside main(), which needs packages that
-    # are not installed; the expectations below are derived by hand from make_lexicon.py:119-143
+def test_build_lexicon_small_cases():
+    # readable cases; the outputs recorded from scripts/make_lexicon.py:119-143 itself are replayed in
+    # tests/test_oracle_golden_tail.py::test_build_lexicon_equals_make_lexicon
     texts = ["the cat sat", "the cat", "a b the", "naïve the don't", "zz zz zz", "the"]
     assert build_lexicon(texts) == ["the", "zz", "cat", "a", "b", "sat"]
     assert build_lexicon(texts, min_freq=2) == ["the", "zz", "cat"]
