@@ -315,6 +315,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse "
                                                              "several ranks on one GPU")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure throughput run)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of a wave per utterance in nsd_step (0 = library's "
+                                                         "choice; 16, 32 or 64)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="seconds after which the self-started ranks of --gpus N are ended")
     return ap.parse_args(argv)
@@ -384,7 +386,7 @@ def worker(args):
     lm = NgramCounts(args.order, floor_vsz=(args.variant == "U")).fit(corpus)
     tables = DeviceTables.from_words(words, lm)
     dec = NSDecoder(tables, args.beam, args.tmax, variant=args.variant, lm_weight=args.beta,
-                    oov_penalty=args.gamma, word_bonus=args.kappa)
+                    oov_penalty=args.gamma, word_bonus=args.kappa, lanes_per_utt=args.lanes)
     tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
     ws = dec.workspace(args.utts)
 

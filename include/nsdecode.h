@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NSD_VERSION        100
+#define NSD_VERSION        101
 #define NSD_V              40
 #define NSD_NBASE          37
 #define NSD_SPACE          36
@@ -85,22 +85,28 @@ typedef struct NsdTrieCSR {            /* host memory */
     uint32_t n_nodes;
 } NsdTrieCSR;
 
-/* Open-addressed (linear probing) tables of host-precomputed fp64 log-probs.
+/* Open-addressed tables of host-precomputed fp64 log-probs.
  * Replaces CharNgramLM.counts/.context and the math.log per n-gram of
  * CharNgramLM.logp (scripts/ns_utils.py:138-150).
  * Keys pack symbol codes 6 bits each, oldest symbol highest:
  *   code = token id + 1 for the 37 base characters, 38 for '^', 39 for '$'.
- * slot index = nsd_hash64(key) & (cap - 1); empty slots hold NSD_KEY_EMPTY. */
+ * Empty slots hold NSD_KEY_EMPTY.
+ *
+ * n-gram table: linear probing from slot nsd_hash64(key) & (cap - 1) (whole-string scoring only). */
 typedef struct NsdGramSlot {           /* key: `order` symbols */
     uint64_t key;
     double   logp;                     /* log((c+1)/(C+|V|+1)) */
 } NsdGramSlot;
 
+/* Context table: two-choice (cuckoo) placement.  With h = nsd_hash64(key), a key sits either in slot
+ * h & (cap - 1) or in slot (h >> 32) & (cap - 1), never anywhere else: a look-up is two independent 32-byte
+ * reads issued together, for a key that is present as for one that is not (the decoder asks mostly for
+ * contexts the corpus never showed, and a wave waits for its slowest lane). */
 typedef struct NsdCtxSlot {            /* key: `order-1` symbols */
     uint64_t key;
-    double   backoff;                  /* log(1/(C+|V|+1)): value of an unseen n-gram in a seen context */
     double   term;                     /* log((c(ctx+'$')+1)/(C+|V|+1)): the terminal n-gram */
     uint64_t ctx_id;                   /* index of this context in ctx_recs */
+    double   backoff;                  /* log(1/(C+|V|+1)): value of an unseen n-gram in a seen context */
 } NsdCtxSlot;
 
 /* The same counts as a context automaton, which is what nsd_step walks: one
@@ -132,7 +138,7 @@ typedef struct NsdNgramHash {          /* host memory */
     uint32_t init_ctx;                 /* id of the context of the empty surface ('^' for order 2, the empty
                                           context for order 1), NSD_CTX_NONE for longer orders */
     uint64_t gram_cap;                 /* power of two */
-    uint64_t ctx_cap;                  /* power of two */
+    uint64_t ctx_cap;                  /* power of two, at most 2^32 */
     const NsdGramSlot *grams;
     const NsdCtxSlot  *ctxs;
     double   unseen;                   /* log(1/(|V|+1)): any n-gram in an unseen context */

@@ -45,7 +45,7 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
     if (order < 0 || order > NSD_MAX_ORDER) return NSD_E_ORDER;
     if (order > 0) {
         if (!lm->grams || !lm->ctxs) return NSD_E_NULL;
-        if (!is_pow2(lm->gram_cap) || !is_pow2(lm->ctx_cap)) return NSD_E_TABLE;
+        if (!is_pow2(lm->gram_cap) || !is_pow2(lm->ctx_cap) || lm->ctx_cap > (1ull << 32)) return NSD_E_TABLE;
         if ((lm->n_ctx_recs && !lm->ctx_recs) || (lm->n_gram_recs && !lm->gram_recs)) return NSD_E_NULL;
         // every automaton edge must stay inside the arrays
         for (uint32_t i = 0; i < lm->n_ctx_recs; ++i) {
@@ -56,8 +56,13 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
         for (uint32_t i = 0; i < lm->n_gram_recs; ++i)
             if (lm->gram_recs[i].next_ctx != NSD_CTX_NONE && lm->gram_recs[i].next_ctx >= lm->n_ctx_recs)
                 return NSD_E_TABLE;
-        for (uint64_t i = 0; i < lm->ctx_cap; ++i)
-            if (lm->ctxs[i].key != NSD_KEY_EMPTY && lm->ctxs[i].ctx_id >= lm->n_ctx_recs) return NSD_E_TABLE;
+        for (uint64_t i = 0; i < lm->ctx_cap; ++i) {
+            // a context key sits in one of its two slots and names a record that exists
+            if (lm->ctxs[i].key == NSD_KEY_EMPTY) continue;
+            const uint64_t m = nsd_mix64(lm->ctxs[i].key);
+            if ((m & (lm->ctx_cap - 1)) != i && ((m >> 32) & (lm->ctx_cap - 1)) != i) return NSD_E_TABLE;
+            if (lm->ctxs[i].ctx_id >= lm->n_ctx_recs) return NSD_E_TABLE;
+        }
         if (lm->init_ctx != NSD_CTX_NONE && lm->init_ctx >= lm->n_ctx_recs) return NSD_E_TABLE;
     }
     // children of every node must stay inside the array
@@ -98,14 +103,28 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
             // a unigram model scores the '^' marker itself: log-prob of the n-gram "^", else the empty
             // context's back-off, else the unseen value
             t->lm_start = lm->unseen;
-            for (uint64_t h = nsd_mix64(0) & (lm->ctx_cap - 1);; h = (h + 1) & (lm->ctx_cap - 1)) {
-                if (lm->ctxs[h].key == 0) { t->lm_start = lm->ctxs[h].backoff; break; }
-                if (lm->ctxs[h].key == NSD_KEY_EMPTY) break;
+            {
+                const uint64_t m = nsd_mix64(0);
+                const uint64_t h1 = m & (lm->ctx_cap - 1), h2 = (m >> 32) & (lm->ctx_cap - 1);
+                if (lm->ctxs[h1].key == 0) t->lm_start = lm->ctxs[h1].backoff;
+                else if (lm->ctxs[h2].key == 0) t->lm_start = lm->ctxs[h2].backoff;
             }
             for (uint64_t h = nsd_mix64(NSD_SYM_HAT) & (lm->gram_cap - 1);; h = (h + 1) & (lm->gram_cap - 1)) {
                 if (lm->grams[h].key == NSD_SYM_HAT) { t->lm_start = lm->grams[h].logp; break; }
                 if (lm->grams[h].key == NSD_KEY_EMPTY) break;
             }
+        }
+        {   // range of the values a look-up can return (bounds of a candidate's score before its look-up)
+            double lo = lm->unseen, hi = lm->unseen;
+            auto see = [&](double v) { if (v < lo) lo = v; if (v > hi) hi = v; };
+            for (uint64_t i = 0; i < lm->gram_cap; ++i)
+                if (lm->grams[i].key != NSD_KEY_EMPTY) see(lm->grams[i].logp);
+            for (uint64_t i = 0; i < lm->ctx_cap; ++i)
+                if (lm->ctxs[i].key != NSD_KEY_EMPTY) { see(lm->ctxs[i].backoff); see(lm->ctxs[i].term); }
+            for (uint32_t i = 0; i < lm->n_ctx_recs; ++i) { see(lm->ctx_recs[i].backoff); see(lm->ctx_recs[i].term); }
+            for (uint32_t i = 0; i < lm->n_gram_recs; ++i) { see(lm->gram_recs[i].logp); see(lm->gram_recs[i].term_next); }
+            t->min_logp = lo;
+            t->max_logp = hi;
         }
         t->gram_mask = lm->gram_cap - 1;
         t->ctx_mask = lm->ctx_cap - 1;

@@ -20,6 +20,7 @@ struct NsdTables {
     double       unseen;
     uint64_t     ctx_sym_mask;   // keeps the last order-1 symbols of a packed context
     double       lm_start;       // LM sum of the empty surface: the '^' window, which exists for order 1 only
+    double       min_logp, max_logp;   // smallest / largest log-prob any table look-up can return
 };
 
 #define NSD_SYM_HAT    38u
@@ -121,6 +122,33 @@ NSD_D float nsd_dpp_half_mirror(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
 }
 
+// fp64 value of the lane at xor-distance d (a power of two below 64) for reductions in which the lanes of every
+// aligned block of d lanes already agree: the mirrored lane of the next larger block then holds what the lane at
+// distance d holds, so distances up to 8 are register moves (DPP) instead of LDS-crossbar permutes.
+template <int D>
+NSD_D double nsd_xchg_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(uint32_t)b, hi = (int)(uint32_t)((uint64_t)b >> 32);
+    if (D == 1) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    } else if (D == 2) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+    } else if (D == 4) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true);       // row_half_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true);
+    } else if (D == 8) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true);       // row_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true);
+    } else {
+        lo = __shfl_xor(lo, D);
+        hi = __shfl_xor(hi, D);
+    }
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+
 // Two exponentials at once with the packed fp32 instructions (v_pk_mul/fma/add_f32 are IEEE per element,
 // so each half has the bits of nsd_det_expf).
 typedef float nsd_f2 __attribute__((ext_vector_type(2)));
@@ -188,15 +216,28 @@ NSD_D bool nsd_gram_find(const NsdTables &t, uint64_t key, double &val)
     }
 }
 
+// The two slots a context key may occupy (two-choice placement): both keys are requested before either is
+// looked at, so a look-up costs one memory round trip whether the key is there or not.
 NSD_D const NsdCtxSlot *nsd_ctx_find(const NsdTables &t, uint64_t key)
 {
-    uint64_t h = nsd_mix64(key) & t.ctx_mask;
-    for (;;) {
-        const uint64_t k = t.ctxs[h].key;
-        if (k == key) return &t.ctxs[h];
-        if (k == NSD_KEY_EMPTY) return nullptr;
-        h = (h + 1) & t.ctx_mask;
-    }
+    const uint64_t m = nsd_mix64(key);
+    const NsdCtxSlot *a = t.ctxs + (m & t.ctx_mask), *b = t.ctxs + ((m >> 32) & t.ctx_mask);
+    const uint64_t ka = a->key, kb = b->key;
+    return ka == key ? a : (kb == key ? b : nullptr);
+}
+
+// id and terminal log-prob of a context (NSD_CTX_NONE / the unseen value when the corpus never showed it); the
+// 20 bytes read of each of the two slots are requested together
+NSD_D void nsd_ctx_lookup(const NsdTables &t, uint64_t key, uint32_t &id, double &term)
+{
+    const uint64_t m = nsd_mix64(key);
+    const NsdCtxSlot *a = t.ctxs + (m & t.ctx_mask), *b = t.ctxs + ((m >> 32) & t.ctx_mask);
+    const ulonglong2 qa = *reinterpret_cast<const ulonglong2 *>(a);    // key, term
+    const ulonglong2 qb = *reinterpret_cast<const ulonglong2 *>(b);
+    const uint32_t ia = (uint32_t)a->ctx_id, ib = (uint32_t)b->ctx_id;
+    const bool ha = qa.x == key, hb = qb.x == key;
+    id = ha ? ia : (hb ? ib : NSD_CTX_NONE);
+    term = ha ? __longlong_as_double((long long)qa.y) : (hb ? __longlong_as_double((long long)qb.y) : t.unseen);
 }
 
 NSD_D double nsd_ctx_backoff(const NsdTables &t, uint64_t ctx)
@@ -269,11 +310,7 @@ NSD_D NsdLmStep nsd_lm_advance(const NsdTables &t, int me, uint64_t ctxe, uint32
             r.lint = t.unseen;
         }
     }
-    if (r.full_new && !resolved) {
-        const NsdCtxSlot *s = nsd_ctx_find(t, r.ctxn);
-        r.next_id = s ? (uint32_t)s->ctx_id : NSD_CTX_NONE;
-        r.term = s ? s->term : t.unseen;
-    }
+    if (r.full_new && !resolved) nsd_ctx_lookup(t, r.ctxn, r.next_id, r.term);
     return r;
 }
 

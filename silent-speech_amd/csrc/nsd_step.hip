@@ -32,6 +32,7 @@
 // inference_emg_llm.py:239-297 (I) and eval_ar.py:243-313 (E) of the
 // reference; all score arithmetic is fp64 in the reference's operation order.
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "nsd_device.h"
 
 namespace {
@@ -112,6 +113,34 @@ NSD_HD uint32_t max_cands_per_beam(int B, int variant)
     const uint32_t lex = NSD_NBASE + (variant == NSD_VARIANT_I ? 0u : 1u);   // 37 characters (+ EOS)
     const uint32_t fb = kfb + (variant == NSD_VARIANT_U ? 1u : 0u);
     return lex > fb ? lex : fb;
+}
+
+// fp64 score of a character candidate: hypothesis score + (log-prob + beta * LM value of the extended text), the LM
+// value being the running sum plus the new n-gram (when its window exists) plus the terminal n-gram (when it
+// exists), added left to right.  Scoring calls it with the table's values, the bounds with the table's extremes;
+// every operation is monotone in lint / term, so the result lies between the two bounds bit for bit.
+NSD_D double char_score(double sb, double lp, double ge, bool has_int, double lint, bool full_new, double term,
+                        bool use_lm, double beta)
+{
+    double add = lp;
+    if (use_lm) {
+        double lg = ge;
+        if (has_int) lg = lg + lint;
+        if (full_new) lg = lg + term;
+        add += beta * lg;
+    }
+    return sb + add;
+}
+
+// the smallest float that is not below x (NaN stays NaN)
+NSD_D float float_not_below(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) {
+        const uint32_t b = __float_as_uint(f);
+        f = __uint_as_float((b >> 31) ? b - 1u : b + 1u);        // one step towards +inf
+    }
+    return f;
 }
 
 template <int G>
@@ -305,6 +334,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 #define NSD_TOC(acc) do { } while (0)
 #endif
     bool err_topk = false;
+    uint32_t scored = 0;                          // candidates [0, scored) already have their key (group-uniform)
 
     auto emit = [&](bool pred, float lp, uint32_t info) {
         const uint64_t gb = gballot(pred);
@@ -350,7 +380,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 // (only offered without a pending one, when effective and stripped state coincide) is
                 // scored on the stripped surface and its transition is only kept for the write phase.
                 NsdLmStep s;
-                s.full_new = false; s.term = 0.0;
+                s.full_new = false; s.has_int = false; s.term = 0.0; s.lint = 0.0;
                 double lgn = 0.0;
                 if (use_lm && !is_eos && (keep || !is_sp)) {
                     const uint64_t ctx = L.bCtx(p);
@@ -375,12 +405,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                         if (!whole) add -= P.gamma;
                         if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
                     }
-                } else if (use_lm) {
-                    double lg = lgn;
-                    if (s.full_new) lg = lg + s.term;
-                    add += P.beta * lg;
+                    score = sb + add;
+                } else {
+                    score = char_score(sb, lp, L.bGe(p), s.has_int, s.lint, s.full_new, s.term, use_lm, P.beta);
                 }
-                score = sb + add;
             }
             if (VARIANT == NSD_VARIANT_E) {
                 L.cScore()[i] = score;
@@ -389,6 +417,138 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 L.cKey()[i] = score;
             }
         }
+    };
+
+    // Pruning key of the not yet scored candidate i with the two table values of its n-gram transition replaced
+    // by `sub_hi` / `sub_lo`: candidates whose key needs no look-up (carried, fall-back, EOS, space) come out
+    // exact, hi == lo.  Same operations in the same order as score_new.
+    auto bounds = [&](uint32_t i, double sub_hi, double sub_lo, double &hi, double &lo) {
+        const uint32_t info = L.cInfo()[i];
+        const uint32_t tok = info & 0x3f, kind = (info >> 6) & 3, p = info >> 14;
+        const double lp = (double)reinterpret_cast<const float *>(L.cKey())[2 * i];
+        const double sb = L.bScore(p);
+        const uint32_t meta = L.bMeta(p);
+        const int glen = (int)(meta >> 8);
+        int Lnew = glen + 1;
+        if (kind == K_CARRY) {
+            hi = lo = sb;
+            Lnew = glen > 1 ? glen : 1;
+        } else if (kind == K_FALLBACK) {
+            hi = lo = sb + (lp - P.gamma);
+        } else if (kind == K_EOS && VARIANT == NSD_VARIANT_U) {
+            hi = lo = sb + lp;
+        } else {
+            const int pend = (meta & NSD_F_PENDING_SPACE) ? 1 : 0;
+            const int ms = 1 + glen - pend;
+            const bool is_eos = kind == K_EOS;
+            const bool is_sp = !is_eos && tok == NSD_SPACE;
+            if (is_eos || is_sp) {
+                const bool whole = (L.bMask(p) >> 37) & 1;
+                double add = lp;
+                double lg = L.bG(p);
+                if (ms + 1 >= order) lg = lg + L.bTermS(p);
+                if (is_eos) {
+                    add -= P.eos_len_nudge * (double)glen;
+                    if (use_lm && glen > 0) add += P.beta * lg;
+                } else {
+                    if (use_lm) add += P.beta * lg;
+                    if (!whole) add -= P.gamma;
+                    if (VARIANT == NSD_VARIANT_E && whole) add += P.kappa;
+                }
+                hi = lo = sb + add;
+            } else {
+                const bool has_int = 1 + glen + 1 >= order, full_new = 1 + glen + 2 >= order;
+                const double ge = L.bGe(p);
+                hi = char_score(sb, lp, ge, has_int, sub_hi, full_new, sub_hi, use_lm, P.beta);
+                lo = char_score(sb, lp, ge, has_int, sub_lo, full_new, sub_lo, use_lm, P.beta);
+            }
+        }
+        if (VARIANT == NSD_VARIANT_E) {
+            const double den = P.len_denom[Lnew];
+            hi = hi / den;
+            lo = lo / den;
+        }
+    };
+
+    // Drop candidates that cannot be among the top-B before a table look-up is spent on them (groups with `want`,
+    // which need C > G; every lane of the wave must call it).  Every candidate's key lies between a lower and an
+    // upper bound that need no look-up (exact keys are their own bounds).  The lanes form >= B cells of neighbouring
+    // lanes, and the lanes of a cell take candidates that lie `cells` apart in the buffer, so that neighbouring
+    // candidates, which tend to share a parent, fall into different cells;
+    // every cell holds a candidate, hence at least B candidates have a key of at least tau = the smallest of the
+    // cells' largest lower bounds, and a candidate whose upper bound is below tau is beaten by B others whatever
+    // the look-ups return.  Survivors are moved to the front in their order (emission order and the scored
+    // prefix are preserved).
+    auto bound_prune = [&](bool want) {
+        NSD_COUNT(dbg_slowthr);
+        const bool up = !(P.beta < 0.0);
+        const double sub_hi = up ? a.tab.max_logp : a.tab.min_logp;
+        const double sub_lo = up ? a.tab.min_logp : a.tab.max_logp;
+        const uint32_t chunks = wave_max(want ? (C + G - 1) / G : 0u);
+        int cells = 1;
+        while (cells < B) cells <<= 1;
+        if (cells > G) cells = G;
+        const int cell = G / cells;               // lanes per cell (contiguous); lane gl takes candidate perm of a chunk
+        const uint32_t perm = (uint32_t)((gl % cell) * cells + gl / cell);
+        double m = -__builtin_inf();
+        auto bound_one = [&](uint32_t i) {
+            if (!(want && i < C)) return;
+            double hi, lo;
+            if (i < scored) {
+                hi = lo = L.cKey()[i];
+            } else {
+                bounds(i, sub_hi, sub_lo, hi, lo);
+                // kept for the second sweep, rounded up (so that it never drops below the fp64 bound)
+                reinterpret_cast<float *>(L.cKey())[2 * i + 1] = float_not_below(hi);
+            }
+            m = lo > m ? lo : m;                   // a NaN bound never raises the threshold
+        };
+        for (uint32_t ch = 0; ch + 1 < chunks; ch += 2) {       // two candidates per lane and trip: their LDS reads overlap
+            bound_one(ch * G + perm);
+            bound_one((ch + 1) * G + perm);
+        }
+        if (chunks & 1u) bound_one((chunks - 1) * G + perm);
+        // largest per cell first (distances below the cell width), then the smallest over the cells
+        auto red = [&](auto dist) {
+            constexpr int D = decltype(dist)::value;
+            if (D < G) {
+                const double o = nsd_xchg_f64<D>(m);
+                m = D < cell ? fmax(m, o) : fmin(m, o);
+            }
+        };
+        red(std::integral_constant<int, 1>{});  red(std::integral_constant<int, 2>{});
+        red(std::integral_constant<int, 4>{});  red(std::integral_constant<int, 8>{});
+        red(std::integral_constant<int, 16>{}); red(std::integral_constant<int, 32>{});
+        const double tau = m;
+        uint32_t n = 0, nsc = 0;
+        for (uint32_t ch = 0; ch < chunks; ++ch) {
+            const uint32_t i = ch * G + gl;
+            const bool valid = want && i < C;
+            uint32_t info = 0;
+            unsigned long long k8 = 0;
+            double sc = 0.0;
+            bool pred = false;
+            if (valid) {
+                info = L.cInfo()[i];
+                k8 = reinterpret_cast<const unsigned long long *>(L.cKey())[i];
+                if (VARIANT == NSD_VARIANT_E) sc = L.cScore()[i];
+                const double hi = i < scored ? __longlong_as_double((long long)k8)
+                                             : (double)__uint_as_float((uint32_t)(k8 >> 32));
+                pred = !(hi < tau);
+            }
+            const uint64_t gb = gballot(pred);
+            const uint32_t pos = n + gprefix(gb);
+            nsc += (uint32_t)__popcll(gballot(pred && i < scored));
+            nsd_wave_sync();                       // the whole chunk is in registers before any of it is overwritten
+            if (pred) {
+                L.cInfo()[pos] = info;
+                reinterpret_cast<unsigned long long *>(L.cKey())[pos] = k8;
+                if (VARIANT == NSD_VARIANT_E) L.cScore()[pos] = sc;
+            }
+            n += (uint32_t)__popcll(gb);
+        }
+        nsd_wave_sync();
+        if (want) { C = n; scored = nsc; }
     };
 
     // top-`nsel` of candidates [0, C): afterwards L.sel(r) = buffer index of rank r (r < nsel), for the
@@ -686,7 +846,6 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const int j = lane & 7;
     const int npass = act ? (nlive + RPP - 1) / RPP : 0;
     const int npass_max = (int)wave_max((uint32_t)npass);
-    uint32_t scored = 0;                          // candidates [0, scored) already have their key
     // logits of the next pass are requested before the current pass is processed
     float xn[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     auto fetch_row = [&](int pass) {
@@ -726,7 +885,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 #pragma unroll
             for (int off = 8; off < G; off <<= 1) add += __shfl_xor(add, off);
             add = __shfl(add, gshift);
-            const bool over = act && C + add > CAP;
+            bool over = act && C + add > CAP;
+            if (__ballot(over && C > (uint32_t)G) != 0) {
+                nsd_wave_sync();
+                bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
+                over = act && C + add > CAP;
+            }
             if (__ballot(over) != 0) {
                 NSD_TIC();
                 // score_new covers every group of the wave; when it does not run, the groups that are not
@@ -785,6 +949,16 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     }
     NSD_STAMP(2);
     nsd_wave_sync();
+    // more candidates than two scoring rounds take: bound them away first (up to that size the sweep costs what
+    // it saves; it is repeated only while the buffer still exceeds two rounds and the last sweep removed something)
+    {
+        bool again = act && C > 2u * (uint32_t)G;
+        for (int it = 0; it < 3 && __ballot(again) != 0; ++it) {
+            const uint32_t before = C;
+            bound_prune(again);
+            again = again && C > 2u * (uint32_t)G && C < before;
+        }
+    }
     // nothing scored or pruned so far and the upper half of the buffer free: transitions can be kept
     const bool kept = act && scored == 0 && 2u * C <= CAP;
     score_new(scored, kept);

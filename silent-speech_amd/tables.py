@@ -22,7 +22,7 @@ KEY_EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 NODE_DTYPE = np.dtype([("mask", "<u8"), ("child_base", "<u4"), ("reserved", "<u4")])
 GRAM_DTYPE = np.dtype([("key", "<u8"), ("logp", "<f8")])
-CTX_DTYPE = np.dtype([("key", "<u8"), ("backoff", "<f8"), ("term", "<f8"), ("ctx_id", "<u8")])
+CTX_DTYPE = np.dtype([("key", "<u8"), ("term", "<f8"), ("ctx_id", "<u8"), ("backoff", "<f8")])
 CTXREC_DTYPE = np.dtype([("backoff", "<f8"), ("term", "<f8"), ("symmask", "<u8"), ("child_base", "<u4"),
                          ("reserved", "<u4")])
 GRAMREC_DTYPE = np.dtype([("logp", "<f8"), ("term_next", "<f8"), ("next_ctx", "<u4"), ("reserved", "<u4")])
@@ -161,6 +161,50 @@ def _place(keys: np.ndarray, cap: int) -> np.ndarray:
     return slot
 
 
+def _place_two_choice(keys: np.ndarray, cap: int, max_kicks: int = 2000):
+    """Slot of every (distinct) key under two-choice (cuckoo) placement: a key goes to slot h & (cap - 1) or to
+    slot (h >> 32) & (cap - 1), h = mix64(key).  Returns None when some key cannot be placed at this capacity."""
+    n = keys.shape[0]
+    h = mix64(keys)
+    h1 = (h & np.uint64(cap - 1)).astype(np.int64)
+    h2 = ((h >> np.uint64(32)) & np.uint64(cap - 1)).astype(np.int64)
+    owner = np.full(cap, -1, dtype=np.int64)
+    slot = np.full(n, -1, dtype=np.int64)
+    pending = np.arange(n)
+    for cand in (h1, h2):                         # first come, first served: most keys settle here
+        if not pending.size:
+            break
+        p = cand[pending]
+        free = owner[p] < 0
+        idx, pos = pending[free], p[free]
+        _, first = np.unique(pos, return_index=True)
+        win = idx[first]
+        owner[cand[win]] = win
+        slot[win] = cand[win]
+        lost = np.ones(pending.size, dtype=bool)
+        lost[np.flatnonzero(free)[first]] = False
+        pending = pending[lost]
+    rng = np.random.RandomState(12345)
+    for k in pending.tolist():                    # the rest: evict along a random walk
+        cur = int(k)
+        pos = int(h1[cur])
+        for _ in range(max_kicks):
+            other = int(owner[pos])
+            owner[pos] = cur
+            slot[cur] = pos
+            if other < 0:
+                cur = -1
+                break
+            cur = other
+            a, b = int(h1[cur]), int(h2[cur])
+            pos = b if pos == a else a
+            if a == b or rng.rand() < 0.02:        # both choices coincide, or break a cycle: restart elsewhere
+                pos = a if rng.rand() < 0.5 else b
+        if cur >= 0:
+            return None
+    return slot
+
+
 class NgramCounts:
     """Character n-gram counts with CharNgramLM's attribute names.
 
@@ -286,12 +330,16 @@ def compile_ngram(lm, floor_vsz: Optional[bool] = None) -> NgramTables:
         sl = _place(gkeys, grams.shape[0])
         grams["key"][sl] = gkeys
         grams["logp"][sl] = gvals
-    # the decoder probes this table for every unseen transition, mostly with keys it does not hold: at a
-    # load of at most 1/4 three of four such probes end at the first (empty) slot
-    ctxs = np.zeros(_capacity(len(ckeys), 4), dtype=CTX_DTYPE)
+    # the decoder asks this table about every unseen transition, mostly for keys it does not hold; two-choice
+    # placement answers with two independent reads either way (no probe chains)
+    cap = _capacity(len(ckeys), 3)
+    sl = _place_two_choice(ckeys, cap) if len(ckeys) else None
+    while len(ckeys) and sl is None:
+        cap *= 2
+        sl = _place_two_choice(ckeys, cap)
+    ctxs = np.zeros(cap, dtype=CTX_DTYPE)
     ctxs["key"] = KEY_EMPTY
     if len(ckeys):
-        sl = _place(ckeys, ctxs.shape[0])
         ctxs["key"][sl] = ckeys
         ctxs["backoff"][sl] = cback
         ctxs["term"][sl] = cterm
@@ -303,7 +351,18 @@ def compile_ngram(lm, floor_vsz: Optional[bool] = None) -> NgramTables:
 # host-side lookups over the flat tables (used by the CPU-only tests of the
 # table compiler; the decoder itself only reads them on the device)
 # ----------------------------------------------------------------------
+def host_find_ctx(table: np.ndarray, key: int) -> int:
+    """Slot of a context key in the two-choice table, or -1."""
+    cap = table.shape[0]
+    h = int(mix64(np.array([key], dtype=np.uint64))[0])
+    for pos in (h & (cap - 1), (h >> 32) & (cap - 1)):
+        if int(table["key"][pos]) == key:
+            return pos
+    return -1
+
+
 def host_find(table: np.ndarray, key: int) -> int:
+    """Slot of an n-gram key in the linear-probing table, or -1."""
     cap = table.shape[0]
     h = int(mix64(np.array([key], dtype=np.uint64))[0]) & (cap - 1)
     keys = table["key"]
@@ -333,7 +392,7 @@ def host_logp(t: NgramTables, text: str) -> float:
             if j >= 0:
                 v = float(t.grams["logp"][j])
         if v is None:
-            j = host_find(t.ctxs, ck) if ck is not None else -1
+            j = host_find_ctx(t.ctxs, ck) if ck is not None else -1
             v = float(t.ctxs["backoff"][j]) if j >= 0 else t.unseen
         total += v
     return total
@@ -364,7 +423,7 @@ def host_automaton_logp(t: NgramTables, text: str) -> float:
     sym_mask = (1 << (6 * (n - 1))) - 1 if n >= 2 else 0
 
     def find(k):
-        j = host_find(t.ctxs, k)
+        j = host_find_ctx(t.ctxs, k)
         return int(t.ctxs["ctx_id"][j]) if j >= 0 else CTX_NONE
 
     if n == 1:
@@ -395,7 +454,7 @@ def host_automaton_logp(t: NgramTables, text: str) -> float:
 # ----------------------------------------------------------------------
 # on-disk format of the replicated tables: one .npz (arrays only, nothing is unpickled on load)
 # ----------------------------------------------------------------------
-TABLE_FORMAT_VERSION = 1
+TABLE_FORMAT_VERSION = 2
 
 
 def save_tables(path: str, nodes: np.ndarray, ngram: Optional[NgramTables]) -> None:

@@ -80,7 +80,7 @@ def test_ngram_tables_empty_lm_probe():
 def test_hash_tables_are_well_formed():
     lm = O.NgramLM(5).fit(synth.make_sentences(synth.make_lexicon(200, 0), 3000, 1))
     t = T.compile_ngram(lm)
-    for tab in (t.grams, t.ctxs):
+    for tab, find in ((t.grams, T.host_find), (t.ctxs, T.host_find_ctx)):
         cap = tab.shape[0]
         assert cap & (cap - 1) == 0
         used = tab["key"] != T.KEY_EMPTY
@@ -88,7 +88,25 @@ def test_hash_tables_are_well_formed():
         keys = tab["key"][used]
         assert len(np.unique(keys)) == len(keys)
         for k in keys[:200]:
-            assert T.host_find(tab, int(k)) >= 0
+            assert find(tab, int(k)) >= 0
+    # every context key sits in one of its two slots, and every seen context is in the table
+    used = np.flatnonzero(t.ctxs["key"] != T.KEY_EMPTY)
+    h = T.mix64(t.ctxs["key"][used])
+    cap = np.uint64(t.ctxs.shape[0] - 1)
+    assert (((h & cap) == used) | (((h >> np.uint64(32)) & cap) == used)).all()
+    assert len(used) == len(t.ctx_recs) == len(lm.context)
+    assert sorted(t.ctxs["ctx_id"][used].tolist()) == list(range(len(used)))
+
+
+def test_two_choice_placement_under_pressure():
+    rng = np.random.RandomState(5)
+    keys = np.unique(rng.randint(0, 2 ** 62, size=40000).astype(np.uint64))
+    cap = 1 << 17                                      # load 0.3: needs evictions, must succeed
+    sl = T._place_two_choice(keys, cap)
+    assert sl is not None and len(np.unique(sl)) == len(keys)
+    h = T.mix64(keys)
+    assert (((h & np.uint64(cap - 1)).astype(np.int64) == sl) | (((h >> np.uint64(32)) & np.uint64(cap - 1)).astype(np.int64) == sl)).all()
+    assert T._place_two_choice(keys, 1 << 15) is None   # more keys than slots
 
 
 def test_library_exports_every_declared_symbol():
@@ -100,7 +118,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     lib.load()
-    assert lib.load().nsd_version() == 100
+    assert lib.load().nsd_version() == 101
     assert b"beam" in lib.load().nsd_strerror(-2)
     # the exported slot hash equals the table builder's
     for k in (0, 1, 12345678901234567, 2 ** 64 - 2):
