@@ -290,27 +290,39 @@ NSD_D NsdLmStep nsd_lm_advance(const NsdTables &t, int me, uint64_t ctxe, uint32
     r.has_int = me + 1 >= order;
     r.full_new = me + 2 >= order;
     r.ctxn = nsd_ctx_shift(t, ctxe, sym);
+    // Either the n-gram is in the automaton (one record: log-prob, terminal log-prob and id of the next context)
+    // or, when the next context has order-1 symbols, that context is looked up in the two-choice table.  Both
+    // kinds of read go through the same two 16-byte + 4-byte loads with lane-specific addresses, outside any
+    // divergent branch, so a scoring round is one memory round trip whatever mix of lanes it holds.
+    const bool seen = r.has_int && ide != NSD_CTX_NONE && ((symmask >> sym) & 1ull);
+    const bool ask = r.full_new && !seen;
+    const char *pa = reinterpret_cast<const char *>(t.gram_recs), *pb = pa;
+    if (seen) {
+        pa = pb = reinterpret_cast<const char *>(t.gram_recs + lmbase + __popcll(symmask & ((1ull << sym) - 1ull)));
+    }
+    if (__builtin_amdgcn_ballot_w64(ask) != 0) {
+        if (ask) {
+            const uint64_t m = nsd_mix64(r.ctxn);
+            pa = reinterpret_cast<const char *>(t.ctxs + (m & t.ctx_mask));
+            pb = reinterpret_cast<const char *>(t.ctxs + ((m >> 32) & t.ctx_mask));
+        }
+    }
+    const ulonglong2 qa = *reinterpret_cast<const ulonglong2 *>(pa);
+    const ulonglong2 qb = *reinterpret_cast<const ulonglong2 *>(pb);
+    const uint32_t ia = *reinterpret_cast<const uint32_t *>(pa + 16), ib = *reinterpret_cast<const uint32_t *>(pb + 16);
     r.next_id = NSD_CTX_NONE;
     r.lint = 0.0;
     r.term = 0.0;
-    bool resolved = false;
-    if (r.has_int) {
-        if (ide != NSD_CTX_NONE) {
-            if ((symmask >> sym) & 1ull) {
-                const NsdGramRec *g = t.gram_recs + lmbase + __popcll(symmask & ((1ull << sym) - 1ull));
-                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(g);     // logp, term_next
-                r.lint = __longlong_as_double((long long)a.x);
-                r.term = __longlong_as_double((long long)a.y);
-                r.next_id = g->next_ctx;
-                resolved = true;
-            } else {
-                r.lint = backoff;
-            }
-        } else {
-            r.lint = t.unseen;
-        }
+    if (r.has_int) r.lint = ide != NSD_CTX_NONE ? backoff : t.unseen;
+    if (seen) {                                   // gram record: logp, term_next | next_ctx
+        r.lint = __longlong_as_double((long long)qa.x);
+        r.term = __longlong_as_double((long long)qa.y);
+        r.next_id = ia;
+    } else if (ask) {                             // context slots: key, term | ctx_id
+        const bool ha = qa.x == r.ctxn, hb = qb.x == r.ctxn;
+        r.next_id = ha ? ia : (hb ? ib : NSD_CTX_NONE);
+        r.term = ha ? __longlong_as_double((long long)qa.y) : (hb ? __longlong_as_double((long long)qb.y) : t.unseen);
     }
-    if (r.full_new && !resolved) nsd_ctx_lookup(t, r.ctxn, r.next_id, r.term);
     return r;
 }
 
