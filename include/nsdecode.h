@@ -316,6 +316,41 @@ int nsd_lm_prior_ce_grad(const NsdTables *t, const float *logits, const int64_t 
 int nsd_kv_reorder(const void *src, void *dst, const uint8_t *backptr, int32_t L, int32_t M, int32_t B, int32_t H,
                    int32_t T, int32_t t, int32_t row_bytes, void *stream);
 
+/* ---- the non-GEMM part of a KV-cached batched step of the AR head ----------------------------------------
+ * EMGTextModel.step (inference_emg_llm.py:83-88) re-runs the frozen LLM over the whole sequence for one
+ * hypothesis at a time.  With a cache, a step feeds ONE token per hypothesis; the dense contractions stay
+ * hipBLASLt, these kernels are what lies between them.  The generated keys / values are never moved: position s
+ * of the generated part is a slab [M, kv_heads, hd] written once (M = N*B hypotheses), and hypothesis m reads,
+ * at position s, the slab row of its ancestor at that step, found through the scorer's back-pointers.
+ * Element type of activations, weights and caches: dtype 0 = fp32, 1 = bf16; arithmetic in fp32. */
+
+/* anc[s, m] (u8 [>= t, M]) = in-beam rank of the hypothesis that hypothesis m (of the beam after scorer step
+ * t-1) descends from at generated position s < t.   backptr device [>= t, M] as written by nsd_step. */
+int nsd_ancestors(const uint8_t *backptr, int32_t t, int32_t N, int32_t B, uint8_t *anc, void *stream);
+
+/* x_out = x + delta (skipped when delta is NULL; x_out may be x); h = w * (x_out * rsqrt(mean(x_out^2) + eps)),
+ * the normalised row rounded to the element type before the weight is applied (LlamaRMSNorm).  rows x hidden. */
+int nsd_add_rmsnorm(const void *x, const void *delta, const void *w, float eps, int32_t rows, int32_t hidden,
+                    int32_t dtype, void *x_out, void *h, void *stream);
+
+/* Rotary embedding (rotate-half form) of the q and k heads of qkv [M, (heads + 2 kv_heads) * hd] with the
+ * step's cos / sin (fp32 [hd], both halves hold the same angles); q to q_out [M, heads, hd], k and v to the
+ * step's slabs k_out / v_out [M, kv_heads, hd] of the generated cache. */
+int nsd_rope_kv_append(const void *qkv, const float *cos_t, const float *sin_t, int32_t M, int32_t heads,
+                       int32_t kvh, int32_t hd, int32_t dtype, void *q_out, void *k_out, void *v_out, void *stream);
+
+/* Attention of the new token of every hypothesis over [context ; generated positions 0..t]:
+ *   q [M, heads, hd] (rotated); kctx / vctx [N, kv_heads, S, hd]: the utterance's context, shared by its B
+ *   hypotheses; kgen / vgen [>= t+1, M, kv_heads, hd]: slabs of the generated positions (position t is the
+ *   hypothesis' own slot, earlier ones go through anc); out [M, heads, hd].
+ * hd: a multiple of 4 (fp32) / 8 (bf16) up to 64, or 128, or 256; heads / kv_heads in {1, 2, 3, 4, 8}. */
+int nsd_attn_step(const void *q, const void *kctx, const void *vctx, const void *kgen, const void *vgen,
+                  const uint8_t *anc, void *out, int32_t N, int32_t B, int32_t heads, int32_t kvh, int32_t hd,
+                  int32_t S, int32_t t, float scale, int32_t dtype, void *stream);
+
+/* out[r, i] = silu(gate_up[r, i]) * gate_up[r, inter + i]  (the SwiGLU between the two MLP contractions). */
+int nsd_swiglu(const void *gate_up, int64_t rows, int32_t inter, int32_t dtype, void *out, void *stream);
+
 /* Row-wise deterministic fp32 log-softmax, the one nsd_step applies
  * (F.log_softmax at scripts/ns_utils.py:227).  x, out device [rows, V]. */
 int nsd_log_softmax(const float *x, int32_t rows, int32_t V, float *out, void *stream);

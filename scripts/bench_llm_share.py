@@ -10,7 +10,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from silent_speech_amd import synthetic as S
-from silent_speech_amd.ar_head import LLAMA_3_2_3B, LlamaDims, TorchLlamaStep
+from silent_speech_amd.ar_head import LLAMA_3_2_3B, HipLlamaStep, LlamaDims, TorchLlamaStep
 from silent_speech_amd.decoder import DeviceTables, NSDecoder
 from silent_speech_amd.tables import NgramCounts
 
@@ -21,6 +21,9 @@ ap.add_argument("--context", type=int, default=96, help="prompt + EMG adapter po
 ap.add_argument("--tmax", type=int, default=64)
 ap.add_argument("--small", action="store_true", help="a 4-layer, 512-wide model (smoke run)")
 ap.add_argument("--variant", default="I")
+ap.add_argument("--head", default="hip", choices=["hip", "torch"],
+                help="hip: everything between the GEMMs in the library's kernels, cache never re-ordered; "
+                     "torch: torch ops + nsd_kv_reorder")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -28,7 +31,7 @@ dims = LlamaDims(512, 4, 8, 2, 64, 1408) if args.small else LLAMA_3_2_3B
 words = S.make_lexicon(200, 0)
 lm = NgramCounts(5, floor_vsz=(args.variant == "U")).fit(S.make_sentences(words, 20000, 1))
 dec = NSDecoder(DeviceTables.from_words(words, lm), args.beam, args.tmax, variant=args.variant, lm_weight=0.05)
-head = TorchLlamaStep(dims, dtype=torch.bfloat16, device=dev, seed=0)
+head = (HipLlamaStep if args.head == "hip" else TorchLlamaStep)(dims, dtype=torch.bfloat16, device=dev, seed=0)
 context = torch.randn(args.utts, args.context, dims.hidden, device=dev, dtype=torch.bfloat16) * 0.5
 
 
@@ -59,6 +62,7 @@ decode(False)
 llm, sc, n_ids = decode(True)
 tl, ts = sum(llm) / len(llm), sum(sc) / len(sc)
 print(json.dumps({
+    "head": args.head,
     "workload": f"{args.utts} utterances x beam {args.beam}, context {args.context}, T_max {args.tmax}, variant {args.variant}, "
                 f"AR head {'small test model' if args.small else 'Llama-3.2-3B-shaped, random bf16 weights'}",
     "llm_step_ms_mean": tl, "llm_step_ms_first_last": [llm[0], llm[-1]],

@@ -220,6 +220,9 @@ class TorchLlamaStep:
 
     # ------------------------------------------------------------------ glue for NSDecoder.decode_batch
     def step_fn_batched(self):
+        return self._step_fn_batched()
+
+    def _step_fn_batched(self):
         """Callable for `NSDecoder.decode_batch(..., needs_ids=False)`: reads the scorer's back-pointers and
         tokens of the previous step from the workspace."""
         def fn(ids, lens, ws):
@@ -230,4 +233,109 @@ class TorchLlamaStep:
             tok = ws.token[t - 1, :self.N * self.B].long()
             tok = torch.where(tok >= self.d.vocab, torch.zeros_like(tok), tok)     # carried / absent slots: any id
             return self.step(tok, backptr=ws.backptr[t - 1, :self.N * self.B])
+        return fn
+
+
+class HipLlamaStep(TorchLlamaStep):
+    """The same step with everything between the dense contractions in HIP kernels of libnsdecode.so
+    (nsd_add_rmsnorm, nsd_rope_kv_append, nsd_attn_step, nsd_swiglu) and a generated-position cache that is never
+    re-ordered: position s is a slab [M, kv_heads, hd] written once, and a hypothesis reads the slab rows of its
+    ancestors, found through the scorer's back-pointer array (nsd_ancestors).  GPU only."""
+
+    _DT = {torch.float32: 0, torch.bfloat16: 1}
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        if self.dtype not in self._DT:
+            raise ValueError("HipLlamaStep stores fp32 or bf16")
+        if self.device.type != "cuda":
+            raise ValueError("HipLlamaStep runs on the GPU only")
+        from . import lib as _lib
+        self._lib, self._L = _lib, _lib.load()
+
+    @torch.no_grad()
+    def encode_context(self, context: torch.Tensor, beam: int, max_new_tokens: int) -> None:
+        super().encode_context(context, beam, max_new_tokens)
+        d, M, T = self.d, self.N * self.B, max(self.T, 1)
+        del self.kg, self.vg
+        kw = dict(dtype=self.dtype, device=self.device)
+        self.kgen = torch.zeros(d.layers, T, M, d.kv_heads, d.head_dim, **kw)
+        self.vgen = torch.zeros(d.layers, T, M, d.kv_heads, d.head_dim, **kw)
+        self.anc = torch.zeros(T, M, dtype=torch.uint8, device=self.device)
+        self._own_bp = torch.zeros(T, M, dtype=torch.uint8, device=self.device)
+        self._buf = {}
+
+    def _tmp(self, name, *shape):
+        b = self._buf.get(name)
+        if b is None or b.shape != shape:
+            b = self._buf[name] = torch.empty(*shape, dtype=self.dtype, device=self.device)
+        return b
+
+    @torch.no_grad()
+    def step(self, tokens: torch.Tensor, parent: Optional[torch.Tensor] = None,
+             backptr: Optional[torch.Tensor] = None, backptr_all: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """As TorchLlamaStep.step.  The parents of the previous scorer step come as `backptr` (u8 [M], in-beam
+        ranks) or `parent` (global indices), and are kept in a [T, M] history of this object; or pass the scorer's
+        own back-pointer array `backptr_all` (u8 [T, M], `Workspace.backptr`) and nothing is copied."""
+        d, t, S, N, B = self.d, self.t, self.S, self.N, self.B
+        M, L, lib, dt = N * B, self._L, self._lib, self._DT[self.dtype]
+        if t >= self.T:
+            raise ValueError("all max_new_tokens steps already ran")
+        st = torch.cuda.current_stream().cuda_stream
+        if t > 0:
+            if backptr_all is None:
+                if backptr is None:
+                    if parent is None:
+                        raise ValueError("the parents of the previous step are needed from the second step on")
+                    backptr = (parent % B).to(torch.uint8)
+                self._own_bp[t - 1] = backptr
+                backptr_all = self._own_bp
+            lib.check(L.nsd_ancestors(backptr_all.data_ptr(), t, N, B, self.anc.data_ptr(), st), "nsd_ancestors")
+        ang = (S + t) * self.inv_freq
+        ang = torch.cat((ang, ang))
+        if self.dtype == torch.float32:
+            cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+        else:                                           # the angles' cos / sin rounded to the storage type, as torch does
+            cos, sin = ang.cos().to(self.dtype).float().contiguous(), ang.sin().to(self.dtype).float().contiguous()
+        x = F.embedding(tokens, self.w["char_embed"]).contiguous()        # [M, hidden]
+        h = self._tmp("h", M, d.hidden)
+        q = self._tmp("q", M, d.heads, d.head_dim)
+        att = self._tmp("att", M, d.heads * d.head_dim)
+        act = self._tmp("act", M, d.intermediate)
+        delta = None
+        for l in range(d.layers):
+            lib.check(L.nsd_add_rmsnorm(x.data_ptr(), delta.data_ptr() if delta is not None else None,
+                                        self.w[f"{l}.ln1"].data_ptr(), d.rms_eps, M, d.hidden, dt, x.data_ptr(),
+                                        h.data_ptr(), st), "nsd_add_rmsnorm")
+            qkv = F.linear(h, self.w[f"{l}.qkv"])
+            lib.check(L.nsd_rope_kv_append(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), M, d.heads, d.kv_heads,
+                                           d.head_dim, dt, q.data_ptr(), self.kgen[l, t].data_ptr(),
+                                           self.vgen[l, t].data_ptr(), st), "nsd_rope_kv_append")
+            lib.check(L.nsd_attn_step(q.data_ptr(), self.kp[l].data_ptr(), self.vp[l].data_ptr(),
+                                      self.kgen[l].data_ptr(), self.vgen[l].data_ptr(), self.anc.data_ptr(),
+                                      att.data_ptr(), N, B, d.heads, d.kv_heads, d.head_dim, S, t, self.scale, dt, st),
+                      "nsd_attn_step")
+            o = F.linear(att, self.w[f"{l}.o"])
+            lib.check(L.nsd_add_rmsnorm(x.data_ptr(), o.data_ptr(), self.w[f"{l}.ln2"].data_ptr(), d.rms_eps, M,
+                                        d.hidden, dt, x.data_ptr(), h.data_ptr(), st), "nsd_add_rmsnorm")
+            gu = F.linear(h, self.w[f"{l}.gate_up"])
+            lib.check(L.nsd_swiglu(gu.data_ptr(), M, d.intermediate, dt, act.data_ptr(), st), "nsd_swiglu")
+            delta = F.linear(act, self.w[f"{l}.down"])
+        lib.check(L.nsd_add_rmsnorm(x.data_ptr(), delta.data_ptr() if delta is not None else None,
+                                    self.w["norm"].data_ptr(), d.rms_eps, M, d.hidden, dt, x.data_ptr(), h.data_ptr(), st),
+                  "nsd_add_rmsnorm")
+        self.t = t + 1
+        return F.linear(h, self.w["lm_head.w"], self.w["lm_head.b"]).float()
+
+    def step_fn_batched(self):
+        """Callable for `NSDecoder.decode_batch(..., needs_ids=False)`: the scorer's back-pointer array is read in
+        place."""
+        def fn(ids, lens, ws):
+            t = ws.steps_run
+            M = self.N * self.B
+            if t == 0:
+                return self.step(torch.full((M,), 37, dtype=torch.int64, device=self.device))
+            tok = ws.token[t - 1, :M].long()
+            tok = torch.where(tok >= self.d.vocab, torch.zeros_like(tok), tok)     # carried / absent slots: any id
+            return self.step(tok, backptr_all=ws.backptr)
         return fn

@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 SO = PKG / "libnsdecode.so"
-SOURCES = ["nsd_step.hip", "nsd_aux.hip", "nsd_prior.hip"]
+SOURCES = ["nsd_step.hip", "nsd_aux.hip", "nsd_prior.hip", "nsd_attn.hip"]
 HEADERS = [CSRC / "nsd_device.h", ROOT / "include" / "nsdecode.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

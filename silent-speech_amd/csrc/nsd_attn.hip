@@ -1,0 +1,391 @@
+// The non-GEMM part of a KV-cached, batched decode step of the AR head (gfx950): what EMGTextModel.step
+// (inference_emg_llm.py:83-88) needs around its dense contractions when all N utterances x B hypotheses of a
+// beam step advance together and the generated keys / values are never moved:
+//   nsd_ancestors       hypothesis m's ancestor slot at every generated position, from the scorer's back-pointers
+//   nsd_add_rmsnorm     residual add + RMSNorm (one wave per row)
+//   nsd_rope_kv_append  rotary embedding of q and k, k / v written to the step's slab of the generated cache
+//   nsd_attn_step       attention of one new token per hypothesis over [context keys shared by the utterance ;
+//                       generated keys addressed through the ancestor table], online softmax, fp32 accumulation
+//   nsd_swiglu          silu(gate) * up
+// Element types: fp32 or bf16 storage (dtype 0 / 1), arithmetic in fp32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nsd_device.h"
+
+namespace {
+
+struct BF16 { uint16_t b; };
+
+template <class T> NSD_D float to_f(T v);
+template <> NSD_D float to_f<float>(float v) { return v; }
+template <> NSD_D float to_f<BF16>(BF16 v) { return __uint_as_float((uint32_t)v.b << 16); }
+
+template <class T> NSD_D T from_f(float v);
+template <> NSD_D float from_f<float>(float v) { return v; }
+template <> NSD_D BF16 from_f<BF16>(float v)
+{
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return BF16{(uint16_t)((u >> 16) | 0x40u)};     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                   // round to nearest even
+    return BF16{(uint16_t)(u >> 16)};
+}
+
+// sixteen bytes of a row as floats: 4 (fp32) or 8 (bf16) elements
+template <class T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    NSD_D static void load(const float *p, float (&o)[8])
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+template <> struct Vec16<BF16> {
+    static constexpr int N = 8;
+    NSD_D static void load(const BF16 *p, float (&o)[8])
+    {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+};
+
+NSD_D float wave_max_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+NSD_D float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d);
+    return v;
+}
+
+// ---------------------------------------------------------------------
+// ancestors: one wave per utterance, the utterance's back-pointers of steps 0..t-1 staged in LDS
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+nsd_ancestors_kernel(const uint8_t *backptr, int t, int M, int B, uint8_t *anc)
+{
+    extern __shared__ unsigned char bp[];
+    const int u = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < t * B; i += 64) bp[i] = backptr[(size_t)(i / B) * M + (size_t)u * B + (i % B)];
+    __syncthreads();
+    if (lane >= B) return;
+    int a = lane;
+    for (int s = t - 1; s >= 0; --s) {
+        int b = bp[s * B + a];
+        if (b >= B) b = 0;                         // slots the beam does not use: any in-range ancestor
+        a = b;
+        anc[(size_t)s * M + (size_t)u * B + lane] = (uint8_t)a;
+    }
+}
+
+// ---------------------------------------------------------------------
+// residual add + RMSNorm: x_out = x (+ delta); h = w * (x_out * rsqrt(mean(x_out^2) + eps)), one wave per row
+// ---------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256)
+nsd_add_rmsnorm_kernel(const T *x, const T *delta, const T *w, float eps, int rows, int hidden, T *x_out, T *h)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T *xr = x + (size_t)row * hidden;
+    const T *dr = delta ? delta + (size_t)row * hidden : nullptr;
+    float ss = 0.0f;
+    for (int i = lane; i < hidden; i += 64) {
+        float v = to_f(xr[i]);
+        if (dr) {
+            v = to_f(from_f<T>(v + to_f(dr[i])));          // the sum is stored in the element type first
+            x_out[(size_t)row * hidden + i] = from_f<T>(v);
+        }
+        ss += v * v;
+    }
+    ss = wave_sum_f(ss);
+    const float inv = rsqrtf(ss / (float)hidden + eps);
+    const T *src = dr ? x_out + (size_t)row * hidden : xr;
+    for (int i = lane; i < hidden; i += 64) {
+        const float v = to_f(src[i]) * inv;
+        h[(size_t)row * hidden + i] = from_f<T>(to_f(w[i]) * to_f(from_f<T>(v)));
+    }
+}
+
+// ---------------------------------------------------------------------
+// rotary embedding (rotate-half form) of q and k; k and v go to the step's slab of the generated cache
+// ---------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256)
+nsd_rope_kv_append_kernel(const T *qkv, const float *cs, const float *sn, int M, int heads, int kvh, int hd,
+                          T *q_out, T *k_out, T *v_out)
+{
+    const int half = hd >> 1;
+    const int per_row = (heads + 2 * kvh) * half;              // one thread per pair of elements
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)M * per_row) return;
+    const int m = (int)(gid / per_row), rem = (int)(gid % per_row);
+    const int head = rem / half, i = rem % half;
+    const T *src = qkv + ((size_t)m * (heads + 2 * kvh) + head) * hd;
+    const float x1 = to_f(src[i]), x2 = to_f(src[i + half]);
+    if (head >= heads + kvh) {                                   // value rows are copied
+        T *dst = v_out + ((size_t)m * kvh + (head - heads - kvh)) * hd;
+        dst[i] = src[i];
+        dst[i + half] = src[i + half];
+        return;
+    }
+    // x * cos + rotate_half(x) * sin, each product rounded before the sum
+    const float a1 = x1 * cs[i], b1 = x2 * sn[i];
+    const float a2 = x2 * cs[i + half], b2 = x1 * sn[i + half];
+    const float o1 = a1 - b1, o2 = a2 + b2;
+    T *dst = head < heads ? q_out + ((size_t)m * heads + head) * hd : k_out + ((size_t)m * kvh + (head - heads)) * hd;
+    dst[i] = from_f<T>(o1);
+    dst[i + half] = from_f<T>(o2);
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+nsd_swiglu_kernel(const T *gu, long long rows, int inter, T *out)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * inter) return;
+    const long long r = gid / inter;
+    const int i = (int)(gid % inter);
+    const float g = to_f(gu[r * 2 * inter + i]), u = to_f(gu[r * 2 * inter + inter + i]);
+    const float s = to_f(from_f<T>(g / (1.0f + expf(-g))));      // silu, stored in the element type
+    out[gid] = from_f<T>(s * u);
+}
+
+// ---------------------------------------------------------------------
+// attention of one new token per hypothesis.  One wave per (hypothesis, kv head): its G = heads / kv_heads
+// query heads share every key / value row.  Keys in chunks of 64 positions: lane = position for q . k (the
+// queries are broadcast from LDS), lane = head dimension for the weighted sum of the values; running maximum
+// and sum of an online softmax.  The waves of a workgroup are the hypotheses of one utterance and one kv
+// head, so the context rows they share stay in that CU's caches.
+// ---------------------------------------------------------------------
+struct AttnArgs {
+    const void *q, *kctx, *vctx, *kgen, *vgen;
+    const uint8_t *anc;
+    void *out;
+    int N, B, heads, kvh, hd, S, t, M;
+    float scale;
+};
+
+template <class T, int G, int EPL>
+__global__ void __launch_bounds__(1024)
+nsd_attn_step_kernel(AttnArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int u = blockIdx.x / a.kvh, h = blockIdx.x % a.kvh;
+    const int r = blockIdx.y * waves + w;
+    if (r >= a.B) return;
+    const int hd = a.hd, M = a.M, S = a.S, t = a.t;
+    const int m = u * a.B + r;
+    const size_t per_wave = (size_t)G * hd * 4 + (size_t)G * 64 * 4 + 64 * 8;
+    float *qs = reinterpret_cast<float *>(smem + (size_t)w * per_wave);       // [G][hd], pre-scaled
+    float *ps = qs + (size_t)G * hd;                                           // [G][64] softmax numerators
+    const T **vrow = reinterpret_cast<const T **>(ps + G * 64);                // [64] value row of each position
+    const T *q = static_cast<const T *>(a.q) + ((size_t)m * a.heads + (size_t)h * G) * hd;
+    for (int i = lane; i < G * hd; i += 64) qs[i] = to_f(q[i]) * a.scale;
+    nsd_wave_sync();
+
+    float mx[G], den[G], acc[G][EPL];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        mx[g] = -__builtin_inff(); den[g] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[g][e] = 0.0f;
+    }
+    const T *kctx = static_cast<const T *>(a.kctx) + ((size_t)u * a.kvh + h) * (size_t)S * hd;
+    const T *vctx = static_cast<const T *>(a.vctx) + ((size_t)u * a.kvh + h) * (size_t)S * hd;
+    const T *kgen = static_cast<const T *>(a.kgen), *vgen = static_cast<const T *>(a.vgen);
+    const int L = S + t + 1;
+    const int d0 = lane * EPL;                                  // this lane's head dimensions in the value sum
+    for (int c0 = 0; c0 < L; c0 += 64) {
+        const int p = c0 + lane;
+        const bool valid = p < L;
+        const T *kr = kctx, *vr = vctx;
+        if (valid) {
+            if (p < S) {
+                kr = kctx + (size_t)p * hd;
+                vr = vctx + (size_t)p * hd;
+            } else {
+                const int s = p - S;
+                const int slot = s == t ? m : u * a.B + (int)a.anc[(size_t)s * M + m];
+                const size_t off = (((size_t)s * M + slot) * a.kvh + h) * hd;
+                kr = kgen + off;
+                vr = vgen + off;
+            }
+        }
+        float sc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) sc[g] = 0.0f;
+        if (valid) {
+            for (int d = 0; d < hd; d += Vec16<T>::N) {
+                float kf[8];
+                Vec16<T>::load(kr + d, kf);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+#pragma unroll
+                    for (int e = 0; e < Vec16<T>::N; ++e) sc[g] = __builtin_fmaf(qs[g * hd + d + e], kf[e], sc[g]);
+                }
+            }
+        }
+        vrow[lane] = vr;
+        float alpha[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float cm = wave_max_f(valid ? sc[g] : -__builtin_inff());
+            const float mn = fmaxf(mx[g], cm);                 // finite: every chunk holds a valid position
+            alpha[g] = expf(mx[g] - mn);
+            const float pe = valid ? expf(sc[g] - mn) : 0.0f;
+            den[g] = den[g] * alpha[g] + wave_sum_f(pe);
+            mx[g] = mn;
+            ps[g * 64 + lane] = pe;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[g][e] *= alpha[g];
+        }
+        nsd_wave_sync();
+        const int n = L - c0 < 64 ? L - c0 : 64;
+        if (d0 < hd) {
+#pragma unroll 4
+            for (int pp = 0; pp < n; ++pp) {
+                const T *v = vrow[pp] + d0;
+                float vf[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) vf[e] = to_f(v[e]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float pw = ps[g * 64 + pp];
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc[g][e] = __builtin_fmaf(pw, vf[e], acc[g][e]);
+                }
+            }
+        }
+        nsd_wave_sync();
+    }
+    if (d0 < hd) {
+        T *o = static_cast<T *>(a.out) + ((size_t)m * a.heads + (size_t)h * G) * hd + d0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[(size_t)g * hd + e] = from_f<T>(acc[g][e] / den[g]);
+        }
+    }
+}
+
+template <class T, int G>
+int launch_attn_g(const AttnArgs &a, hipStream_t s)
+{
+    const int hd = a.hd;
+    const size_t per_wave = (size_t)G * hd * 4 + (size_t)G * 64 * 4 + 64 * 8;
+    int waves = a.B < 16 ? a.B : 16;
+    while (waves > 1 && per_wave * waves > 65536) --waves;
+    if (per_wave > 65536) return NSD_E_SIZE;
+    const dim3 grid((unsigned)(a.N * a.kvh), (unsigned)((a.B + waves - 1) / waves));
+    const dim3 block(64 * waves);
+    const size_t lds = per_wave * waves;
+    if (hd <= 64) hipLaunchKernelGGL((nsd_attn_step_kernel<T, G, 1>), grid, block, lds, s, a);
+    else if (hd <= 128) hipLaunchKernelGGL((nsd_attn_step_kernel<T, G, 2>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((nsd_attn_step_kernel<T, G, 4>), grid, block, lds, s, a);
+    return (int)hipGetLastError();
+}
+
+template <class T>
+int launch_attn(const AttnArgs &a, hipStream_t s)
+{
+    switch (a.heads / a.kvh) {
+    case 1: return launch_attn_g<T, 1>(a, s);
+    case 2: return launch_attn_g<T, 2>(a, s);
+    case 3: return launch_attn_g<T, 3>(a, s);
+    case 4: return launch_attn_g<T, 4>(a, s);
+    case 8: return launch_attn_g<T, 8>(a, s);
+    default: return NSD_E_SIZE;
+    }
+}
+
+} // namespace
+
+extern "C" int nsd_ancestors(const uint8_t *backptr, int32_t t, int32_t N, int32_t B, uint8_t *anc, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || t < 0 || t > NSD_MAX_STEPS) return NSD_E_SIZE;
+    if (N == 0 || t == 0) return NSD_OK;
+    if (!backptr || !anc) return NSD_E_NULL;
+    hipLaunchKernelGGL(nsd_ancestors_kernel, dim3((unsigned)N), dim3(64), (size_t)t * B, (hipStream_t)stream,
+                       backptr, t, N * B, B, anc);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nsd_add_rmsnorm(const void *x, const void *delta, const void *w, float eps, int32_t rows, int32_t hidden,
+                               int32_t dtype, void *x_out, void *h, void *stream)
+{
+    if (rows < 0 || hidden < 1 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
+    if (rows == 0) return NSD_OK;
+    if (!x || !w || !h || (delta && !x_out)) return NSD_E_NULL;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(nsd_add_rmsnorm_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)x,
+                           (const float *)delta, (const float *)w, eps, rows, hidden, (float *)x_out, (float *)h);
+    else
+        hipLaunchKernelGGL(nsd_add_rmsnorm_kernel<BF16>, grid, block, 0, (hipStream_t)stream, (const BF16 *)x,
+                           (const BF16 *)delta, (const BF16 *)w, eps, rows, hidden, (BF16 *)x_out, (BF16 *)h);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nsd_rope_kv_append(const void *qkv, const float *cos_t, const float *sin_t, int32_t M, int32_t heads,
+                                  int32_t kvh, int32_t hd, int32_t dtype, void *q_out, void *k_out, void *v_out,
+                                  void *stream)
+{
+    if (M < 0 || heads < 1 || kvh < 1 || hd < 2 || (hd & 1) || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
+    if (M == 0) return NSD_OK;
+    if (!qkv || !cos_t || !sin_t || !q_out || !k_out || !v_out) return NSD_E_NULL;
+    const long long n = (long long)M * (heads + 2 * kvh) * (hd / 2);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(nsd_rope_kv_append_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)qkv,
+                           cos_t, sin_t, M, heads, kvh, hd, (float *)q_out, (float *)k_out, (float *)v_out);
+    else
+        hipLaunchKernelGGL(nsd_rope_kv_append_kernel<BF16>, grid, block, 0, (hipStream_t)stream, (const BF16 *)qkv,
+                           cos_t, sin_t, M, heads, kvh, hd, (BF16 *)q_out, (BF16 *)k_out, (BF16 *)v_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nsd_swiglu(const void *gate_up, int64_t rows, int32_t inter, int32_t dtype, void *out, void *stream)
+{
+    if (rows < 0 || inter < 1 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
+    if (rows == 0) return NSD_OK;
+    if (!gate_up || !out) return NSD_E_NULL;
+    const long long n = rows * inter;
+    if ((n + 255) / 256 > 0x7fffffffll) return NSD_E_SIZE;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(nsd_swiglu_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)gate_up,
+                           (long long)rows, inter, (float *)out);
+    else
+        hipLaunchKernelGGL(nsd_swiglu_kernel<BF16>, grid, block, 0, (hipStream_t)stream, (const BF16 *)gate_up,
+                           (long long)rows, inter, (BF16 *)out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nsd_attn_step(const void *q, const void *kctx, const void *vctx, const void *kgen, const void *vgen,
+                             const uint8_t *anc, void *out, int32_t N, int32_t B, int32_t heads, int32_t kvh, int32_t hd,
+                             int32_t S, int32_t t, float scale, int32_t dtype, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || heads < 1 || kvh < 1 || heads % kvh || S < 0 || t < 0 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
+    // sixteen-byte key loads and whole lanes in the value sum
+    if (hd < 4 || hd > 256 || hd % (dtype ? 8 : 4) || (hd > 64 && hd != 128 && hd != 256)) return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!q || !kgen || !vgen || !out || (S > 0 && (!kctx || !vctx)) || (t > 0 && !anc)) return NSD_E_NULL;
+    AttnArgs a;
+    a.q = q; a.kctx = kctx; a.vctx = vctx; a.kgen = kgen; a.vgen = vgen; a.anc = anc; a.out = out;
+    a.N = N; a.B = B; a.heads = heads; a.kvh = kvh; a.hd = hd; a.S = S; a.t = t; a.M = N * B; a.scale = scale;
+    return dtype == 0 ? launch_attn<float>(a, (hipStream_t)stream) : launch_attn<BF16>(a, (hipStream_t)stream);
+}

@@ -56,7 +56,8 @@ EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "ns
            "nsd_tables_order", "nsd_state_init", "nsd_step", "nsd_backtrace", "nsd_gather_ids",
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
            "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad", "nsd_kv_reorder",
-           "nsd_shutdown", "nsd_decode_synth_noalloc"]
+           "nsd_shutdown", "nsd_decode_synth_noalloc", "nsd_ancestors", "nsd_add_rmsnorm", "nsd_rope_kv_append",
+           "nsd_attn_step", "nsd_swiglu"]
 
 _lib = None
 
@@ -93,6 +94,11 @@ def load():
                                    vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.nsd_decode_synth_noalloc.argtypes = [vp, C.POINTER(Params), u64, i64, vp, vp, i32, C.c_float, i32, i32, i32,
                                            vp, vp, vp, vp]
+    L.nsd_ancestors.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.nsd_add_rmsnorm.argtypes = [vp, vp, vp, C.c_float, i32, i32, i32, vp, vp, vp]
+    L.nsd_rope_kv_append.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.nsd_attn_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp]
+    L.nsd_swiglu.argtypes = [vp, i64, i32, i32, vp, vp]
     L.nsd_rerank_lm.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
     L.nsd_kv_reorder.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.nsd_cond_dist.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]

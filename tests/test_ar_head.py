@@ -26,8 +26,10 @@ def _reference_step(llm, char_embed, lm_head, context, ids):
         return lm_head(h)[0]
 
 
-def _run(device, use_backptr=False):
-    from silent_speech_amd.ar_head import TorchLlamaStep
+def _run(device, use_backptr=False, hip=False):
+    from silent_speech_amd.ar_head import HipLlamaStep, TorchLlamaStep
+    if hip:
+        TorchLlamaStep = HipLlamaStep                         # noqa: F811  (same interface)
     llm, char_embed, lm_head = _reference_setup()
     N, B, S, T = 3, 4, 9, 6
     torch.manual_seed(1)
@@ -90,3 +92,94 @@ def test_kv_reorder_equals_index_select():
         assert torch.equal(dst[:, :, :, :t], want)
         assert bool((dst[:, :, :, t:] == 7.0).all())          # positions past t are left alone
 
+
+
+@pytest.mark.gpu
+def test_hip_step_matches_full_sequence_forward_gpu():
+    """The step whose non-GEMM part runs in the library's kernels (ancestor table instead of a cache re-ordering,
+    fused add + RMSNorm, rotary embedding + cache append, attention over [shared context ; ancestor rows], SwiGLU)
+    against transformers' LlamaModel over the whole sequence per hypothesis, fp32, same tolerance."""
+    assert _run("cuda", hip=True) < 2e-4
+    assert _run("cuda", use_backptr=True, hip=True) < 2e-4
+
+
+def _attn_reference(q, kctx, vctx, kgen, vgen, anc, N, B, S, t, scale):
+    """Plain torch fp64: per hypothesis, keys = context rows of its utterance + its ancestors' slab rows."""
+    M, heads, hd = q.shape
+    kvh = kgen.shape[2]
+    g = heads // kvh
+    out = torch.zeros(M, heads, hd, dtype=torch.float64)
+    for m in range(M):
+        u = m // B
+        slots = [u * B + int(anc[s, m]) for s in range(t)] + [m]
+        for h in range(kvh):
+            k = torch.cat([kctx[u, h].double(), torch.stack([kgen[s, slots[s], h] for s in range(t + 1)]).double()])
+            v = torch.cat([vctx[u, h].double(), torch.stack([vgen[s, slots[s], h] for s in range(t + 1)]).double()])
+            for j in range(g):
+                p = torch.softmax((k @ q[m, h * g + j].double()) * scale, 0)
+                out[m, h * g + j] = p @ v
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,N,B,heads,kvh,hd,S,t", [
+    (torch.float32, 2, 4, 4, 2, 16, 9, 5), (torch.float32, 1, 1, 1, 1, 4, 0, 0), (torch.float32, 2, 17, 8, 1, 64, 70, 3),
+    (torch.bfloat16, 2, 16, 24, 8, 128, 96, 63), (torch.bfloat16, 1, 33, 6, 2, 128, 130, 40),
+    (torch.bfloat16, 3, 5, 4, 1, 256, 7, 64), (torch.float32, 2, 3, 3, 3, 32, 64, 0),
+])
+def test_attention_step_kernel(dtype, N, B, heads, kvh, hd, S, t):
+    from silent_speech_amd import lib
+    L = lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(hd + t)
+    M, T = N * B, t + 2
+    r = lambda *s: torch.randn(*s, generator=g).to(dtype)
+    q, kctx, vctx = r(M, heads, hd), r(N, kvh, max(S, 1), hd)[:, :, :S].contiguous(), r(N, kvh, max(S, 1), hd)[:, :, :S].contiguous()
+    kgen, vgen = r(T, M, kvh, hd), r(T, M, kvh, hd)
+    bp = torch.randint(0, B, (T, M), generator=g, dtype=torch.uint8)
+    bp[:, ::7] = 200                                            # slots a beam does not use: clamped to rank 0
+    anc = torch.zeros(T, M, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(L.nsd_ancestors(bp.to(dev).data_ptr(), t, N, B, anc.data_ptr(), st), "nsd_ancestors")
+    want_anc = torch.zeros(T, M, dtype=torch.uint8)
+    for m in range(M):
+        a = m % B
+        for s in range(t - 1, -1, -1):
+            b = int(bp[s, (m // B) * B + a])
+            a = b if b < B else 0
+            want_anc[s, m] = a
+    assert torch.equal(anc.cpu()[:t], want_anc[:t])
+    out = torch.zeros(M, heads, hd, dtype=dtype, device=dev)
+    scale = 1.0 / hd ** 0.5
+    dq, dk, dv, dkg, dvg = (x.to(dev) for x in (q, kctx if S else torch.zeros(1, dtype=dtype), vctx if S else torch.zeros(1, dtype=dtype), kgen, vgen))
+    lib.check(L.nsd_attn_step(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dkg.data_ptr(), dvg.data_ptr(), anc.data_ptr(),
+                              out.data_ptr(), N, B, heads, kvh, hd, S, t, scale, 0 if dtype == torch.float32 else 1, st),
+              "nsd_attn_step")
+    want = _attn_reference(q, kctx, vctx, kgen, vgen, want_anc, N, B, S, t, scale)
+    err = float((out.cpu().double() - want).abs().max())
+    assert err < (2e-5 if dtype == torch.float32 else 2e-2), err
+
+
+@pytest.mark.gpu
+def test_hip_step_equals_torch_step_bf16():
+    """A mid-size bf16 model (head_dim 128, three query heads per kv head, as Llama-3.2-3B): the fused step
+    against the torch-only step through several re-ordered steps."""
+    from silent_speech_amd.ar_head import HipLlamaStep, LlamaDims, TorchLlamaStep
+    dims = LlamaDims(hidden=768, layers=3, heads=6, kv_heads=2, head_dim=128, intermediate=1024)
+    dev = torch.device("cuda", 0)
+    a = TorchLlamaStep(dims, dtype=torch.bfloat16, device=dev, seed=5)
+    b = HipLlamaStep(dims, dtype=torch.bfloat16, device=dev, weights={k: v.clone() for k, v in a.w.items()})
+    N, B, S, T = 3, 16, 40, 8
+    ctx = torch.randn(N, S, dims.hidden, device=dev, dtype=torch.bfloat16) * 0.5
+    a.encode_context(ctx, B, T)
+    b.encode_context(ctx, B, T)
+    rs = np.random.RandomState(0)
+    tok = torch.full((N * B,), 37, dtype=torch.int64, device=dev)
+    bp = None
+    for t in range(T):
+        la = a.step(tok, backptr=bp)
+        lb = b.step(tok, backptr=bp)
+        scale = float(la.abs().max())
+        assert float((la - lb).abs().max()) < 0.04 * max(scale, 1.0), t
+        bp = torch.from_numpy(rs.randint(0, B, N * B).astype(np.uint8)).to(dev)
+        tok = torch.from_numpy(rs.randint(0, 37, N * B)).to(dev)
