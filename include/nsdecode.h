@@ -329,7 +329,8 @@ int nsd_kv_reorder(const void *src, void *dst, const uint8_t *backptr, int32_t L
 int nsd_ancestors(const uint8_t *backptr, int32_t t, int32_t N, int32_t B, uint8_t *anc, void *stream);
 
 /* x_out = x + delta (skipped when delta is NULL; x_out may be x); h = w * (x_out * rsqrt(mean(x_out^2) + eps)),
- * the normalised row rounded to the element type before the weight is applied (LlamaRMSNorm).  rows x hidden. */
+ * the normalised row rounded to the element type before the weight is applied (LlamaRMSNorm).  rows x hidden,
+ * hidden a multiple of 4 (fp32) / 8 (bf16). */
 int nsd_add_rmsnorm(const void *x, const void *delta, const void *w, float eps, int32_t rows, int32_t hidden,
                     int32_t dtype, void *x_out, void *h, void *stream);
 
@@ -343,12 +344,13 @@ int nsd_rope_kv_append(const void *qkv, const float *cos_t, const float *sin_t, 
  *   q [M, heads, hd] (rotated); kctx / vctx [N, kv_heads, S, hd]: the utterance's context, shared by its B
  *   hypotheses; kgen / vgen [>= t+1, M, kv_heads, hd]: slabs of the generated positions (position t is the
  *   hypothesis' own slot, earlier ones go through anc); out [M, heads, hd].
- * hd: a multiple of 4 (fp32) / 8 (bf16) up to 64, or 128, or 256; heads / kv_heads in {1, 2, 3, 4, 8}. */
+ * hd: a power of two, 4 (fp32) / 8 (bf16) to 256; heads / kv_heads in {1, 2, 3, 4, 8}. */
 int nsd_attn_step(const void *q, const void *kctx, const void *vctx, const void *kgen, const void *vgen,
                   const uint8_t *anc, void *out, int32_t N, int32_t B, int32_t heads, int32_t kvh, int32_t hd,
                   int32_t S, int32_t t, float scale, int32_t dtype, void *stream);
 
-/* out[r, i] = silu(gate_up[r, i]) * gate_up[r, inter + i]  (the SwiGLU between the two MLP contractions). */
+/* out[r, i] = silu(gate_up[r, i]) * gate_up[r, inter + i]  (the SwiGLU between the two MLP contractions);
+ * inter a multiple of 4 (fp32) / 8 (bf16). */
 int nsd_swiglu(const void *gate_up, int64_t rows, int32_t inter, int32_t dtype, void *out, void *stream);
 
 /* Row-wise deterministic fp32 log-softmax, the one nsd_step applies

@@ -88,32 +88,58 @@ nsd_ancestors_kernel(const uint8_t *backptr, int t, int M, int B, uint8_t *anc)
 }
 
 // ---------------------------------------------------------------------
-// residual add + RMSNorm: x_out = x (+ delta); h = w * (x_out * rsqrt(mean(x_out^2) + eps)), one wave per row
+// residual add + RMSNorm: x_out = x (+ delta); h = w * (x_out * rsqrt(mean(x_out^2) + eps)), one wave per row,
+// sixteen bytes per lane and access (hidden must be a multiple of the 4 / 8 elements that makes)
 // ---------------------------------------------------------------------
+template <class T> struct Store16;
+template <> struct Store16<float> {
+    NSD_D static void store(float *p, const float (&v)[8]) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Store16<BF16> {
+    NSD_D static void store(BF16 *p, const float (&v)[8])
+    {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)from_f<BF16>(v[2 * i]).b | ((uint32_t)from_f<BF16>(v[2 * i + 1]).b << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
 template <class T>
 __global__ void __launch_bounds__(256)
 nsd_add_rmsnorm_kernel(const T *x, const T *delta, const T *w, float eps, int rows, int hidden, T *x_out, T *h)
 {
+    constexpr int VN = Vec16<T>::N;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T *xr = x + (size_t)row * hidden;
     const T *dr = delta ? delta + (size_t)row * hidden : nullptr;
+    T *xo = x_out + (size_t)row * hidden;
     float ss = 0.0f;
-    for (int i = lane; i < hidden; i += 64) {
-        float v = to_f(xr[i]);
+    for (int i = lane * VN; i < hidden; i += 64 * VN) {
+        float v[8];
+        Vec16<T>::load(xr + i, v);
         if (dr) {
-            v = to_f(from_f<T>(v + to_f(dr[i])));          // the sum is stored in the element type first
-            x_out[(size_t)row * hidden + i] = from_f<T>(v);
+            float d[8];
+            Vec16<T>::load(dr + i, d);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] = to_f(from_f<T>(v[e] + d[e]));     // the sum is stored in the element type
+            Store16<T>::store(xo + i, v);
         }
-        ss += v * v;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) ss += v[e] * v[e];
     }
     ss = wave_sum_f(ss);
     const float inv = rsqrtf(ss / (float)hidden + eps);
-    const T *src = dr ? x_out + (size_t)row * hidden : xr;
-    for (int i = lane; i < hidden; i += 64) {
-        const float v = to_f(src[i]) * inv;
-        h[(size_t)row * hidden + i] = from_f<T>(to_f(w[i]) * to_f(from_f<T>(v)));
+    const T *src = dr ? xo : xr;
+    for (int i = lane * VN; i < hidden; i += 64 * VN) {
+        float v[8], g[8];
+        Vec16<T>::load(src + i, v);
+        Vec16<T>::load(w + i, g);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = g[e] * to_f(from_f<T>(v[e] * inv));
+        Store16<T>::store(h + (size_t)row * hidden + i, v);
     }
 }
 
@@ -152,13 +178,21 @@ template <class T>
 __global__ void __launch_bounds__(256)
 nsd_swiglu_kernel(const T *gu, long long rows, int inter, T *out)
 {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= rows * inter) return;
-    const long long r = gid / inter;
-    const int i = (int)(gid % inter);
-    const float g = to_f(gu[r * 2 * inter + i]), u = to_f(gu[r * 2 * inter + inter + i]);
-    const float s = to_f(from_f<T>(g / (1.0f + expf(-g))));      // silu, stored in the element type
-    out[gid] = from_f<T>(s * u);
+    constexpr int VN = Vec16<T>::N;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte vector per thread
+    const int per_row = inter / VN;
+    if (gid >= rows * per_row) return;
+    const long long r = gid / per_row;
+    const int i = (int)(gid % per_row) * VN;
+    float g[8], u[8];
+    Vec16<T>::load(gu + r * 2 * inter + i, g);
+    Vec16<T>::load(gu + r * 2 * inter + inter + i, u);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+        const float s = to_f(from_f<T>(g[e] / (1.0f + expf(-g[e]))));            // silu, stored in the element type
+        g[e] = s * u[e];
+    }
+    Store16<T>::store(out + r * inter + i, g);
 }
 
 // ---------------------------------------------------------------------
@@ -176,10 +210,46 @@ struct AttnArgs {
     float scale;
 };
 
-template <class T, int G, int EPL>
+// q . k over one 16-byte piece of a key row: the queries lie in LDS in their storage type (every lane reads the
+// same address: a broadcast), bf16 pairs go through the packed dot-product instruction
+template <class T, int G> struct QDot;
+template <int G> struct QDot<float, G> {
+    NSD_D static void run(const float *qs, int hd, int d, const float *kr, float (&sc)[G])
+    {
+        const float4 k = *reinterpret_cast<const float4 *>(kr + d);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 q = *reinterpret_cast<const float4 *>(qs + g * hd + d);
+            sc[g] = __builtin_fmaf(q.x, k.x, sc[g]);
+            sc[g] = __builtin_fmaf(q.y, k.y, sc[g]);
+            sc[g] = __builtin_fmaf(q.z, k.z, sc[g]);
+            sc[g] = __builtin_fmaf(q.w, k.w, sc[g]);
+        }
+    }
+};
+typedef __bf16 nsd_bf2 __attribute__((ext_vector_type(2)));
+template <int G> struct QDot<BF16, G> {
+    NSD_D static void run(const BF16 *qs, int hd, int d, const BF16 *kr, float (&sc)[G])
+    {
+        const uint4 k = *reinterpret_cast<const uint4 *>(kr + d);
+        const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(qs + g * hd + d);
+            const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sc[g] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nsd_bf2, qw[e]), __builtin_bit_cast(nsd_bf2, kw[e]),
+                                                        sc[g], false);
+        }
+    }
+};
+
+template <class T, int G>
 __global__ void __launch_bounds__(1024)
 nsd_attn_step_kernel(AttnArgs a)
 {
+    constexpr int VN = Vec16<T>::N;                             // elements of a 16-byte piece
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int u = blockIdx.x / a.kvh, h = blockIdx.x % a.kvh;
@@ -187,30 +257,34 @@ nsd_attn_step_kernel(AttnArgs a)
     if (r >= a.B) return;
     const int hd = a.hd, M = a.M, S = a.S, t = a.t;
     const int m = u * a.B + r;
-    const size_t per_wave = (size_t)G * hd * 4 + (size_t)G * 64 * 4 + 64 * 8;
-    float *qs = reinterpret_cast<float *>(smem + (size_t)w * per_wave);       // [G][hd], pre-scaled
-    float *ps = qs + (size_t)G * hd;                                           // [G][64] softmax numerators
+    const size_t q_bytes = ((size_t)G * hd * sizeof(T) + 15) & ~(size_t)15;
+    const size_t per_wave = q_bytes + (size_t)G * 64 * 4 + 64 * 8;
+    T *qs = reinterpret_cast<T *>(smem + (size_t)w * per_wave);               // [G][hd]
+    float *ps = reinterpret_cast<float *>(smem + (size_t)w * per_wave + q_bytes);   // [G][64] softmax numerators
     const T **vrow = reinterpret_cast<const T **>(ps + G * 64);                // [64] value row of each position
     const T *q = static_cast<const T *>(a.q) + ((size_t)m * a.heads + (size_t)h * G) * hd;
-    for (int i = lane; i < G * hd; i += 64) qs[i] = to_f(q[i]) * a.scale;
+    for (int i = lane; i < G * hd; i += 64) qs[i] = q[i];
     nsd_wave_sync();
 
-    float mx[G], den[G], acc[G][EPL];
+    // value sum: LP lanes share a position (16 bytes of the row each), 64 / LP positions advance together
+    const int LP = hd / VN;                                     // a power of two up to 64
+    const int PPAR = 64 / LP;
+    const int vd = (lane % LP) * VN, vp0 = lane / LP;
+    float mx[G], den[G], acc[G][VN];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         mx[g] = -__builtin_inff(); den[g] = 0.0f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[g][e] = 0.0f;
+        for (int e = 0; e < VN; ++e) acc[g][e] = 0.0f;
     }
     const T *kctx = static_cast<const T *>(a.kctx) + ((size_t)u * a.kvh + h) * (size_t)S * hd;
     const T *vctx = static_cast<const T *>(a.vctx) + ((size_t)u * a.kvh + h) * (size_t)S * hd;
     const T *kgen = static_cast<const T *>(a.kgen), *vgen = static_cast<const T *>(a.vgen);
     const int L = S + t + 1;
-    const int d0 = lane * EPL;                                  // this lane's head dimensions in the value sum
     for (int c0 = 0; c0 < L; c0 += 64) {
         const int p = c0 + lane;
         const bool valid = p < L;
-        const T *kr = kctx, *vr = vctx;
+        const T *kr = kgen, *vr = vgen;
         if (valid) {
             if (p < S) {
                 kr = kctx + (size_t)p * hd;
@@ -227,55 +301,55 @@ nsd_attn_step_kernel(AttnArgs a)
 #pragma unroll
         for (int g = 0; g < G; ++g) sc[g] = 0.0f;
         if (valid) {
-            for (int d = 0; d < hd; d += Vec16<T>::N) {
-                float kf[8];
-                Vec16<T>::load(kr + d, kf);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-#pragma unroll
-                    for (int e = 0; e < Vec16<T>::N; ++e) sc[g] = __builtin_fmaf(qs[g * hd + d + e], kf[e], sc[g]);
-                }
-            }
+#pragma unroll 4
+            for (int d = 0; d < hd; d += VN) QDot<T, G>::run(qs, hd, d, kr, sc);
         }
         vrow[lane] = vr;
         float alpha[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float cm = wave_max_f(valid ? sc[g] : -__builtin_inff());
+            const float sv = sc[g] * a.scale;
+            const float cm = wave_max_f(valid ? sv : -__builtin_inff());
             const float mn = fmaxf(mx[g], cm);                 // finite: every chunk holds a valid position
             alpha[g] = expf(mx[g] - mn);
-            const float pe = valid ? expf(sc[g] - mn) : 0.0f;
+            const float pe = valid ? expf(sv - mn) : 0.0f;
             den[g] = den[g] * alpha[g] + wave_sum_f(pe);
             mx[g] = mn;
             ps[g * 64 + lane] = pe;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[g][e] *= alpha[g];
+            for (int e = 0; e < VN; ++e) acc[g][e] *= alpha[g];
         }
         nsd_wave_sync();
         const int n = L - c0 < 64 ? L - c0 : 64;
-        if (d0 < hd) {
-#pragma unroll 4
-            for (int pp = 0; pp < n; ++pp) {
-                const T *v = vrow[pp] + d0;
-                float vf[EPL];
+#pragma unroll 2
+        for (int pp = vp0; pp < n; pp += PPAR) {
+            float vf[8];
+            Vec16<T>::load(vrow[pp] + vd, vf);
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) vf[e] = to_f(v[e]);
+            for (int g = 0; g < G; ++g) {
+                const float pw = ps[g * 64 + pp];
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float pw = ps[g * 64 + pp];
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) acc[g][e] = __builtin_fmaf(pw, vf[e], acc[g][e]);
-                }
+                for (int e = 0; e < VN; ++e) acc[g][e] = __builtin_fmaf(pw, vf[e], acc[g][e]);
             }
         }
         nsd_wave_sync();
     }
-    if (d0 < hd) {
-        T *o = static_cast<T *>(a.out) + ((size_t)m * a.heads + (size_t)h * G) * hd + d0;
+    // the position groups' partial sums meet in the lanes of group 0
+    for (int d = LP; d < 64; d <<= 1) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[(size_t)g * hd + e] = from_f<T>(acc[g][e] / den[g]);
+            for (int e = 0; e < VN; ++e) acc[g][e] += __shfl_xor(acc[g][e], d);
+        }
+    }
+    if (vp0 == 0) {
+        T *o = static_cast<T *>(a.out) + ((size_t)m * a.heads + (size_t)h * G) * hd + vd;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float ov[8];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) ov[e] = acc[g][e] / den[g];
+            Store16<T>::store(o + (size_t)g * hd, ov);
         }
     }
 }
@@ -283,17 +357,13 @@ nsd_attn_step_kernel(AttnArgs a)
 template <class T, int G>
 int launch_attn_g(const AttnArgs &a, hipStream_t s)
 {
-    const int hd = a.hd;
-    const size_t per_wave = (size_t)G * hd * 4 + (size_t)G * 64 * 4 + 64 * 8;
+    const size_t q_bytes = ((size_t)G * a.hd * sizeof(T) + 15) & ~(size_t)15;
+    const size_t per_wave = q_bytes + (size_t)G * 64 * 4 + 64 * 8;
     int waves = a.B < 16 ? a.B : 16;
     while (waves > 1 && per_wave * waves > 65536) --waves;
     if (per_wave > 65536) return NSD_E_SIZE;
     const dim3 grid((unsigned)(a.N * a.kvh), (unsigned)((a.B + waves - 1) / waves));
-    const dim3 block(64 * waves);
-    const size_t lds = per_wave * waves;
-    if (hd <= 64) hipLaunchKernelGGL((nsd_attn_step_kernel<T, G, 1>), grid, block, lds, s, a);
-    else if (hd <= 128) hipLaunchKernelGGL((nsd_attn_step_kernel<T, G, 2>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((nsd_attn_step_kernel<T, G, 4>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((nsd_attn_step_kernel<T, G>), grid, dim3(64 * waves), per_wave * waves, s, a);
     return (int)hipGetLastError();
 }
 
@@ -326,7 +396,7 @@ extern "C" int nsd_ancestors(const uint8_t *backptr, int32_t t, int32_t N, int32
 extern "C" int nsd_add_rmsnorm(const void *x, const void *delta, const void *w, float eps, int32_t rows, int32_t hidden,
                                int32_t dtype, void *x_out, void *h, void *stream)
 {
-    if (rows < 0 || hidden < 1 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
+    if (rows < 0 || hidden < 1 || (dtype != 0 && dtype != 1) || hidden % (dtype ? 8 : 4)) return NSD_E_SIZE;
     if (rows == 0) return NSD_OK;
     if (!x || !w || !h || (delta && !x_out)) return NSD_E_NULL;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
@@ -359,10 +429,10 @@ extern "C" int nsd_rope_kv_append(const void *qkv, const float *cos_t, const flo
 
 extern "C" int nsd_swiglu(const void *gate_up, int64_t rows, int32_t inter, int32_t dtype, void *out, void *stream)
 {
-    if (rows < 0 || inter < 1 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
+    if (rows < 0 || inter < 1 || (dtype != 0 && dtype != 1) || inter % (dtype ? 8 : 4)) return NSD_E_SIZE;
     if (rows == 0) return NSD_OK;
     if (!gate_up || !out) return NSD_E_NULL;
-    const long long n = rows * inter;
+    const long long n = rows * (inter / (dtype ? 8 : 4));
     if ((n + 255) / 256 > 0x7fffffffll) return NSD_E_SIZE;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dtype == 0)
@@ -380,8 +450,11 @@ extern "C" int nsd_attn_step(const void *q, const void *kctx, const void *vctx, 
 {
     if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
     if (N < 0 || heads < 1 || kvh < 1 || heads % kvh || S < 0 || t < 0 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
-    // sixteen-byte key loads and whole lanes in the value sum
-    if (hd < 4 || hd > 256 || hd % (dtype ? 8 : 4) || (hd > 64 && hd != 128 && hd != 256)) return NSD_E_SIZE;
+    // rows are read in 16-byte pieces, hd / piece lanes per row in the value sum: a power of two of pieces
+    {
+        const int vn = dtype ? 8 : 4;
+        if (hd < vn || hd > 256 || (hd & (hd - 1))) return NSD_E_SIZE;
+    }
     if (N == 0) return NSD_OK;
     if (!q || !kgen || !vgen || !out || (S > 0 && (!kctx || !vctx)) || (t > 0 && !anc)) return NSD_E_NULL;
     AttnArgs a;
