@@ -317,6 +317,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure throughput run)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wave per utterance in nsd_step (0 = library's "
                                                          "choice; 16, 32 or 64)")
+    ap.add_argument("--lds-trie", type=int, default=0, help="node records of the upper trie levels every workgroup "
+                                                            "stages in LDS (0 = none, the default)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="seconds after which the self-started ranks of --gpus N are ended")
     return ap.parse_args(argv)
@@ -386,7 +388,8 @@ def worker(args):
     lm = NgramCounts(args.order, floor_vsz=(args.variant == "U")).fit(corpus)
     tables = DeviceTables.from_words(words, lm)
     dec = NSDecoder(tables, args.beam, args.tmax, variant=args.variant, lm_weight=args.beta,
-                    oov_penalty=args.gamma, word_bonus=args.kappa, lanes_per_utt=args.lanes)
+                    oov_penalty=args.gamma, word_bonus=args.kappa, lanes_per_utt=args.lanes,
+                    lds_trie_nodes=args.lds_trie)
     tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
     ws = dec.workspace(args.utts)
 

@@ -39,6 +39,7 @@ extern "C" {
 #define NSD_MAX_BEAM       64
 #define NSD_MAX_STEPS      128
 #define NSD_MAX_ORDER      10
+#define NSD_MAX_LDS_TRIE_NODES 1024
 #define NSD_NODE_DEAD      0xFFFFFFFFu
 #define NSD_KEY_EMPTY      0xFFFFFFFFFFFFFFFFull
 #define NSD_TOKEN_CARRY    0xFFu     /* "no token this step": a finished hypothesis carried over */
@@ -162,7 +163,10 @@ typedef struct NsdParams {
     int32_t min_len_for_eos;           /* eval_ar.py:226 (variant E only) */
     int32_t lanes_per_utt;             /* 0 = choose from N and B; else 16, 32 or 64 (>= B): lanes of a wave
                                           that work on one utterance (a tuning knob, results do not depend on it) */
-    int32_t reserved;
+    int32_t lds_trie_nodes;            /* 0 = trie records are read from memory (default).  n > 0: every workgroup first
+                                          copies the first n node records (breadth-first: the upper trie levels) to LDS
+                                          and hypotheses at those nodes read them there (a tuning knob, measured not to
+                                          pay; results do not depend on it); at most NSD_MAX_LDS_TRIE_NODES */
     double  beta;                      /* lm_weight   */
     double  gamma;                     /* oov_penalty */
     double  kappa;                     /* word_bonus  (variant E) */

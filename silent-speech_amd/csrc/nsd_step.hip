@@ -67,6 +67,7 @@ struct StepArgs {
     int32_t      N, B;
     uint32_t     lds_per_utt;
     uint32_t     cap;            // candidate buffer entries per utterance
+    uint32_t     lds_nodes;      // trie node records every workgroup stages at the front of its LDS (0 = none)
 };
 
 // One utterance's LDS region.  Hypothesis fields are interleaved in 104-byte records (one address per
@@ -222,6 +223,16 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     }
     const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
 
+    // optional: the upper trie levels (the first node records in breadth-first order) copied to LDS by the whole
+    // workgroup, before any wave leaves
+    const uint32_t KN = a.lds_nodes;
+    if (KN) {
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(smem);
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.tab.nodes);
+        for (uint32_t i = threadIdx.x; i < KN; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+
     if (act && (um & NSD_U_DONE)) {
         if (a.in.score != a.out.score) {
             if (gl < nbeams) {
@@ -258,7 +269,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const bool use_lm = P.use_lm != 0 && a.tab.order > 0;
     const int order = a.tab.order;
     const uint32_t CAP = a.cap;
-    GroupLds L = carve<G>(smem + ((size_t)wid * UPW + g) * a.lds_per_utt, B, CAP, VARIANT == NSD_VARIANT_E);
+    GroupLds L = carve<G>(smem + (size_t)KN * 16 + ((size_t)wid * UPW + g) * a.lds_per_utt, B, CAP, VARIANT == NSD_VARIANT_E);
 
     // ---------------- phase 1: hypothesis state -> LDS ----------------
     bool my_live = false;
@@ -283,7 +294,10 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         double bo = 0.0, term_s = 0.0;
         const bool in_lex = my_live && !(flags & NSD_F_DEAD) && node != NSD_NODE_DEAD;
         ulonglong2 nrec = {0ull, 0ull};
-        if (in_lex) nrec = *reinterpret_cast<const ulonglong2 *>(&a.tab.nodes[node]);
+        if (in_lex) {
+            if (node < KN) nrec = reinterpret_cast<const ulonglong2 *>(smem)[node];
+            else nrec = *reinterpret_cast<const ulonglong2 *>(&a.tab.nodes[node]);
+        }
         if (use_lm && in_lex) {
             const int pend = (flags & NSD_F_PENDING_SPACE) ? 1 : 0;
             const int ms = 1 + glen - pend;                        // symbols in '^' + stripped surface
@@ -1078,19 +1092,21 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
     const uint32_t lds_per_wave = a.lds_per_utt * UPW;
     // waves per workgroup: the count (4, 2 or 1) that lets most waves share a CU's 160 KiB of LDS, among
     // those whose workgroup stays within the 64 KiB of dynamic LDS a launch may ask for without opting in
+    const uint32_t lds_fixed = a.lds_nodes * 16u;
     int waves = 1, best = 0;
     for (int w = 4; w >= 1; w >>= 1) {
-        if (lds_per_wave * (uint32_t)w > 65536u) continue;
-        const int per_cu = (int)(163840u / (lds_per_wave * (uint32_t)w)) * w;
+        const uint32_t tot = lds_fixed + lds_per_wave * (uint32_t)w;
+        if (tot > 65536u) continue;
+        const int per_cu = (int)(163840u / tot) * w;
         if (per_cu > best) { best = per_cu; waves = w; }
     }
     const long long n_waves = ((long long)N + UPW - 1) / UPW;
     const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
     if (ev0 || ev1)      // the events take the kernel's own start / end timestamps (no marker packets in between)
         hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves),
-                              lds_per_wave * (uint32_t)waves, s, ev0, ev1, 0, a, p);
+                              lds_fixed + lds_per_wave * (uint32_t)waves, s, ev0, ev1, 0, a, p);
     else
-        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves), lds_per_wave * (uint32_t)waves, s, a, p);
+        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves), lds_fixed + lds_per_wave * (uint32_t)waves, s, a, p);
 }
 
 template <int VARIANT>
@@ -1098,6 +1114,13 @@ static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s
 {
     const int G = nsd_step_group(a.B, N, p.lanes_per_utt);
     a.lds_per_utt = (uint32_t)nsd_step_lds_per_utt(a.B, G, p.variant, &a.cap);
+    {   // staged trie records: what was asked for, within the trie, the documented maximum and a workgroup's LDS
+        uint32_t kn = p.lds_trie_nodes > 0 ? (uint32_t)p.lds_trie_nodes : 0u;
+        if (kn > a.tab.n_nodes) kn = a.tab.n_nodes;
+        if (kn > NSD_MAX_LDS_TRIE_NODES) kn = NSD_MAX_LDS_TRIE_NODES;
+        while (kn && kn * 16u + a.lds_per_utt * (uint32_t)(64 / G) > 65536u) kn >>= 1;
+        a.lds_nodes = kn;
+    }
     switch (G) {
     case 16: launch_gv<16, VARIANT>(a, p, N, s, ev0, ev1); break;
     case 32: launch_gv<32, VARIANT>(a, p, N, s, ev0, ev1); break;

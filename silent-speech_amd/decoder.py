@@ -131,7 +131,7 @@ class NSDecoder:
     def __init__(self, tables: DeviceTables, beam: int, max_new_tokens: int, *, variant: str = "U",
                  lm_weight: float = 0.3, oov_penalty: float = 1.0, allow_eos_anytime: bool = True,
                  word_bonus: float = 0.0, length_penalty_alpha: float = 0.6, min_len_for_eos: int = 8,
-                 use_lm: Optional[bool] = None, device=None, lanes_per_utt: int = 0):
+                 use_lm: Optional[bool] = None, device=None, lanes_per_utt: int = 0, lds_trie_nodes: int = 0):
         _require_cuda()
         if variant not in _lib.VARIANTS:
             raise ValueError("variant must be 'U', 'I' or 'E'")
@@ -148,7 +148,7 @@ class NSDecoder:
         self.params = _lib.make_params(variant, use_lm=use_lm and tables.order > 0, beta=lm_weight,
                                        gamma=oov_penalty, kappa=word_bonus, alpha=length_penalty_alpha,
                                        min_len_for_eos=min_len_for_eos, allow_eos_anytime=allow_eos_anytime,
-                                       lanes_per_utt=lanes_per_utt)
+                                       lanes_per_utt=lanes_per_utt, lds_trie_nodes=lds_trie_nodes)
 
     # -- low level ---------------------------------------------------------
     def workspace(self, N: int, with_masks: bool = False) -> Workspace:

@@ -41,7 +41,7 @@ class NgramHash(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("variant", C.c_int32), ("use_lm", C.c_int32), ("allow_eos_anytime", C.c_int32),
-                ("min_len_for_eos", C.c_int32), ("lanes_per_utt", C.c_int32), ("reserved", C.c_int32),
+                ("min_len_for_eos", C.c_int32), ("lanes_per_utt", C.c_int32), ("lds_trie_nodes", C.c_int32),
                 ("beta", C.c_double), ("gamma", C.c_double),
                 ("kappa", C.c_double), ("eos_len_nudge", C.c_double), ("len_denom", C.c_double * (MAX_STEPS + 4))]
 
@@ -118,9 +118,10 @@ def check(code: int, what: str) -> None:
 
 def make_params(variant: str, *, use_lm: bool, beta: float, gamma: float, kappa: float = 0.0,
                 alpha: float = 0.6, min_len_for_eos: int = 8, allow_eos_anytime: bool = True,
-                lanes_per_utt: int = 0) -> Params:
+                lanes_per_utt: int = 0, lds_trie_nodes: int = 0) -> Params:
     p = Params()
     p.lanes_per_utt = int(lanes_per_utt)
+    p.lds_trie_nodes = int(lds_trie_nodes)
     p.variant = VARIANTS[variant]
     p.use_lm = int(bool(use_lm))
     p.allow_eos_anytime = int(bool(allow_eos_anytime))

@@ -810,3 +810,34 @@ def test_largest_lds_footprints_of_the_length_normalised_copy(dev, beam, lanes, 
     ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)
     assert err is None
     _compare_with_trace(ws, ids, lens, scores, ref, case["name"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,beam,lanes", [("I", 16, 0), ("U", 32, 0), ("E", 8, 16), ("I", 16, 32)])
+def test_trie_levels_staged_in_lds_change_nothing(dev, variant, beam, lanes):
+    """The upper trie levels copied to LDS by every workgroup (a tuning knob of the launcher): same parents, tokens,
+    masks and fp64 scores as with every node record read from memory, on a lexicon deeper than what is staged."""
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    words = synth.make_lexicon(4000, 3, synth.BASE_CHARS[:36], 2, 9)
+    corpus = synth.make_sentences(words, 2000, 4)
+    tg, tl = _pack_targets(synth.make_sentences(words, 300, 5, 2, 4))
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    tables = DeviceTables.from_words(words, O.NgramLM(5, floor_vsz=(variant == "U")).fit(corpus))
+    outs = []
+    for kn in (0, 100, 1024, 5000):
+        dec = NSDecoder(tables, beam, 30, variant=variant, lm_weight=0.05, word_bonus=0.35, min_len_for_eos=4,
+                        lanes_per_utt=lanes, lds_trie_nodes=kn)
+        ws = dec.workspace(300, with_masks=True)
+        ids, lens, sc = dec.decode_synth(tgd, tld, base_seed=8, margin=7.0, ws=ws, check_every=0)
+        torch.cuda.synchronize()
+        outs.append([x.cpu().numpy().copy() for x in (ids, lens, sc, ws.backptr, ws.token, ws.masks)])
+    for o in outs[1:]:
+        assert (o[1] == outs[0][1]).all() and (o[0] == outs[0][0]).all()
+        assert (o[2].view(np.int64) == outs[0][2].view(np.int64)).all()
+        assert (o[5] == outs[0][5]).all()
+    ref = cbind.Model(words, corpus, 5, variant == "U").decode_synth(
+        variant=variant, beam=beam, max_new_tokens=30, beta=0.05, gamma=1.0, kappa=0.35, min_len_for_eos=4, margin=7.0,
+        base_seed=8, targets=tg, target_lens=tl, trace=False)
+    assert (ref["lens"] == outs[2][1]).all()
+    for u in range(300):
+        assert (ref["ids"][u, :ref["lens"][u]] == outs[2][0][u, :ref["lens"][u]]).all(), u
