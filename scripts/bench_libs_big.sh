@@ -1,11 +1,14 @@
 #!/bin/bash
-# Experimental builds side by side at a batch far beyond what the chip holds: bench.py --utts $UTTS once per library.
-UTTS=${UTTS:-131072}
+# Experimental builds side by side on the 131072-utterance batch (one GPU's share of the 1M-utterance configuration).
+mkdir -p gpurun_out
+for rep in 1 2; do
 for so in "$@"; do
-  NSDECODE_LIB=$PWD/$so timeout -k 10 300 python bench.py --utts $UTTS --steps 6 --warmup 2 --no-cpu > gpurun_out/bb_$(basename $so).log 2>&1 || { tail -3 gpurun_out/bb_$(basename $so).log; exit 1; }
+  NSDECODE_LIB=$PWD/$so timeout -k 10 300 python bench.py --no-cpu --utts 131072 --steps 4 --warmup 1 --timed-decodes 2 > gpurun_out/bb_$(basename $so).log 2>gpurun_out/bb_$(basename $so).err || { tail -3 gpurun_out/bb_$(basename $so).err; exit 1; }
   python - "$so" gpurun_out/bb_$(basename $so).log <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-print(sys.argv[1], "I ms/decode %.3f launch %.2f us frac %.3f" % (d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"]))
+print(sys.argv[1], "131072 utts: I launch %.1f us frac %.3f | U launch %.1f us" % (
+    d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["variant_U"]["roofline"].get("avg_launch_us", float("nan"))))
 PY
+done
 done
