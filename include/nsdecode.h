@@ -348,10 +348,23 @@ int nsd_rope_kv_append(const void *qkv, const float *cos_t, const float *sin_t, 
  *   q [M, heads, hd] (rotated); kctx / vctx [N, kv_heads, S, hd]: the utterance's context, shared by its B
  *   hypotheses; kgen / vgen [>= t+1, M, kv_heads, hd]: slabs of the generated positions (position t is the
  *   hypothesis' own slot, earlier ones go through anc); out [M, heads, hd].
+ *   part_o / part_m / part_l: NULL, or the softmax state of the context part as nsd_attn_ctx left it
+ *   (fp32 [M*heads, hd], [M*heads], [M*heads]); the context is then not read again (kctx / vctx may be NULL).
  * hd: a power of two, 4 (fp32) / 8 (bf16) to 256; heads / kv_heads in {1, 2, 3, 4, 8}. */
 int nsd_attn_step(const void *q, const void *kctx, const void *vctx, const void *kgen, const void *vgen,
                   const uint8_t *anc, void *out, int32_t N, int32_t B, int32_t heads, int32_t kvh, int32_t hd,
-                  int32_t S, int32_t t, float scale, int32_t dtype, void *stream);
+                  int32_t S, int32_t t, float scale, int32_t dtype, const float *part_o, const float *part_m,
+                  const float *part_l, void *stream);
+
+/* The context part of that attention on the matrix cores (bf16 only): the B hypotheses of an utterance and the
+ * query heads of a kv head share the context keys, so scores and weighted sums are small dense products
+ * (v_mfma_f32_16x16x32_bf16).  kctx_pad [N, kv_heads, S32, hd]: context keys, rows S..S32-1 zero; vctx_t
+ * [N, kv_heads, hd, S32]: context values transposed (keys contiguous), columns S..S32-1 zero; S32 a multiple of
+ * 32, at most 256; hd 64 or 128.  Leaves per query row the unnormalised weighted value sum, the maximum and the
+ * sum of the weights (part_o fp32 [M*heads, hd], part_m / part_l fp32 [M*heads]) for nsd_attn_step to continue. */
+int nsd_attn_ctx(const void *q, const void *kctx_pad, const void *vctx_t, int32_t N, int32_t B, int32_t heads,
+                 int32_t kvh, int32_t hd, int32_t S, int32_t S32, float scale, float *part_o, float *part_m,
+                 float *part_l, void *stream);
 
 /* out[r, i] = silu(gate_up[r, i]) * gate_up[r, inter + i]  (the SwiGLU between the two MLP contractions);
  * inter a multiple of 4 (fp32) / 8 (bf16). */

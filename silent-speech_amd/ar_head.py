@@ -244,8 +244,9 @@ class HipLlamaStep(TorchLlamaStep):
 
     _DT = {torch.float32: 0, torch.bfloat16: 1}
 
-    def __init__(self, *a, **kw):
+    def __init__(self, *a, use_mfma: bool = True, **kw):
         super().__init__(*a, **kw)
+        self.use_mfma = bool(use_mfma)
         if self.dtype not in self._DT:
             raise ValueError("HipLlamaStep stores fp32 or bf16")
         if self.device.type != "cuda":
@@ -264,6 +265,24 @@ class HipLlamaStep(TorchLlamaStep):
         self.anc = torch.zeros(T, M, dtype=torch.uint8, device=self.device)
         self._own_bp = torch.zeros(T, M, dtype=torch.uint8, device=self.device)
         self._buf = {}
+        # context part on the matrix cores (bf16, head_dim 64 / 128, up to 256 context positions): keys padded to a
+        # multiple of 32 rows, values transposed; per query row the softmax state the per-hypothesis kernel continues
+        S32 = (self.S + 31) // 32 * 32
+        self.mfma_ctx = (self.dtype == torch.bfloat16 and d.head_dim in (64, 128) and 0 < self.S and S32 <= 256
+                         and self.use_mfma)
+        if self.mfma_ctx:
+            self.S32 = S32
+            self.kpad, self.vt = [], []
+            for l in range(d.layers):
+                kp = torch.zeros(self.N, d.kv_heads, S32, d.head_dim, **kw)
+                kp[:, :, :self.S] = self.kp[l]
+                vt = torch.zeros(self.N, d.kv_heads, d.head_dim, S32, **kw)
+                vt[:, :, :, :self.S] = self.vp[l].transpose(-1, -2)
+                self.kpad.append(kp)
+                self.vt.append(vt)
+            self.part_o = torch.empty(M * d.heads, d.head_dim, dtype=torch.float32, device=self.device)
+            self.part_m = torch.empty(M * d.heads, dtype=torch.float32, device=self.device)
+            self.part_l = torch.empty(M * d.heads, dtype=torch.float32, device=self.device)
 
     def _tmp(self, name, *shape):
         b = self._buf.get(name)
@@ -311,10 +330,15 @@ class HipLlamaStep(TorchLlamaStep):
             lib.check(L.nsd_rope_kv_append(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), M, d.heads, d.kv_heads,
                                            d.head_dim, dt, q.data_ptr(), self.kgen[l, t].data_ptr(),
                                            self.vgen[l, t].data_ptr(), st), "nsd_rope_kv_append")
+            po = pm = pl = None
+            if self.mfma_ctx:
+                po, pm, pl = self.part_o.data_ptr(), self.part_m.data_ptr(), self.part_l.data_ptr()
+                lib.check(L.nsd_attn_ctx(q.data_ptr(), self.kpad[l].data_ptr(), self.vt[l].data_ptr(), N, B, d.heads,
+                                         d.kv_heads, d.head_dim, S, self.S32, self.scale, po, pm, pl, st), "nsd_attn_ctx")
             lib.check(L.nsd_attn_step(q.data_ptr(), self.kp[l].data_ptr(), self.vp[l].data_ptr(),
                                       self.kgen[l].data_ptr(), self.vgen[l].data_ptr(), self.anc.data_ptr(),
-                                      att.data_ptr(), N, B, d.heads, d.kv_heads, d.head_dim, S, t, self.scale, dt, st),
-                      "nsd_attn_step")
+                                      att.data_ptr(), N, B, d.heads, d.kv_heads, d.head_dim, S, t, self.scale, dt,
+                                      po, pm, pl, st), "nsd_attn_step")
             o = F.linear(att, self.w[f"{l}.o"])
             lib.check(L.nsd_add_rmsnorm(x.data_ptr(), o.data_ptr(), self.w[f"{l}.ln2"].data_ptr(), d.rms_eps, M,
                                         d.hidden, dt, x.data_ptr(), h.data_ptr(), st), "nsd_add_rmsnorm")

@@ -208,6 +208,9 @@ struct AttnArgs {
     void *out;
     int N, B, heads, kvh, hd, S, t, M;
     float scale;
+    // when given: softmax state of the context part (nsd_attn_ctx): unnormalised weighted value sums, running
+    // maxima and sums per query row; this kernel then starts at the first generated position
+    const float *part_o, *part_m, *part_l;
 };
 
 // q . k over one 16-byte piece of a key row: the queries lie in LDS in their storage type (every lane reads the
@@ -281,7 +284,21 @@ nsd_attn_step_kernel(AttnArgs a)
     const T *vctx = static_cast<const T *>(a.vctx) + ((size_t)u * a.kvh + h) * (size_t)S * hd;
     const T *kgen = static_cast<const T *>(a.kgen), *vgen = static_cast<const T *>(a.vgen);
     const int L = S + t + 1;
-    for (int c0 = 0; c0 < L; c0 += 64) {
+    int first = 0;
+    if (a.part_o) {
+        first = S;
+        const size_t row0 = (size_t)m * a.heads + (size_t)h * G;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            mx[g] = a.part_m[row0 + g];
+            den[g] = a.part_l[row0 + g];
+            if (vp0 == 0) {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[g][e] = a.part_o[(row0 + g) * hd + vd + e];
+            }
+        }
+    }
+    for (int c0 = first; c0 < L; c0 += 64) {
         const int p = c0 + lane;
         const bool valid = p < L;
         const T *kr = kgen, *vr = vgen;
@@ -352,6 +369,142 @@ nsd_attn_step_kernel(AttnArgs a)
             Store16<T>::store(o + (size_t)g * hd, ov);
         }
     }
+}
+
+// ---------------------------------------------------------------------
+// context part of the attention on the matrix cores (bf16).  The B hypotheses of an utterance and the G query
+// heads of a kv head share the S context keys: [B*G x hd] x [hd x S] and [B*G x S] x [S x hd] are small dense
+// products.  One wave per tile of 16 query rows; v_mfma_f32_16x16x32_bf16 with the keys as the A operand, so that
+// the scores come out transposed - a lane holds, for ONE query row, four keys of every 16-key tile - which is the
+// A-operand layout of the second product (weights x values) with no lane movement; the values are stored
+// transposed ([hd, S], keys contiguous) so that their B fragments are 8-byte reads.  Keys are padded to a multiple
+// of 32 with zero rows.  Output: unnormalised sums, maxima and sums per query row, which nsd_attn_step continues.
+// ---------------------------------------------------------------------
+typedef __bf16 nsd_bf8 __attribute__((ext_vector_type(8)));
+typedef float nsd_f4 __attribute__((ext_vector_type(4)));
+
+struct CtxArgs {
+    const BF16 *q, *kpad, *vt;
+    float *po, *pm, *pl;
+    int N, B, heads, kvh, S, S32;
+    float scale;
+};
+
+template <int NP, int HD>
+__global__ void __launch_bounds__(256)
+nsd_attn_ctx_kernel(CtxArgs a)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int u = blockIdx.x / a.kvh, h = blockIdx.x % a.kvh;
+    const int G = a.heads / a.kvh, R = a.B * G;                 // query rows of this (utterance, kv head)
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const BF16 *K = a.kpad + ((size_t)u * a.kvh + h) * (size_t)a.S32 * HD;
+    const BF16 *Vt = a.vt + ((size_t)u * a.kvh + h) * (size_t)HD * a.S32;
+    for (int r0 = w * 16; r0 < R; r0 += waves * 16) {
+        // this lane's query row (B operand of the first product, row of the softmax)
+        const bool rv = r0 + c16 < R;
+        const int rho = rv ? r0 + c16 : 0;
+        const size_t qrow = (size_t)(u * a.B + rho / G) * a.heads + (size_t)h * G + (size_t)(rho % G);
+        const BF16 *qp = a.q + qrow * HD + 8 * g4;
+        nsd_bf8 qf[HD / 32];
+#pragma unroll
+        for (int kc = 0; kc < HD / 32; ++kc) qf[kc] = __builtin_bit_cast(nsd_bf8, *reinterpret_cast<const uint4 *>(qp + 32 * kc));
+        // scores, transposed: st[nt][reg] = key (16 nt + 4 g4 + reg) . query row c16
+        nsd_f4 st[2 * NP];
+#pragma unroll
+        for (int nt = 0; nt < 2 * NP; ++nt) {
+            nsd_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const BF16 *kp = K + (size_t)(nt * 16 + c16) * HD + 8 * g4;
+#pragma unroll
+            for (int kc = 0; kc < HD / 32; ++kc)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(nsd_bf8, *reinterpret_cast<const uint4 *>(kp + 32 * kc)), qf[kc], acc, 0, 0, 0);
+            st[nt] = acc;
+        }
+        float mrow = -__builtin_inff();
+#pragma unroll
+        for (int nt = 0; nt < 2 * NP; ++nt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = nt * 16 + 4 * g4 + e;
+                const float v = key < a.S ? st[nt][e] * a.scale : -__builtin_inff();
+                st[nt][e] = v;
+                mrow = fmaxf(mrow, v);
+            }
+        }
+        mrow = fmaxf(mrow, __shfl_xor(mrow, 16));
+        mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+        float lrow = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < 2 * NP; ++nt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = expf(st[nt][e] - mrow);       // 0 for the padded keys
+                st[nt][e] = pe;
+                lrow += pe;
+            }
+        }
+        lrow += __shfl_xor(lrow, 16);
+        lrow += __shfl_xor(lrow, 32);
+        // weights as A fragments: k-slot 8 g4 + j of pair np is key 32 np + 4 g4 + j (j < 4), 32 np + 16 + 4 g4 + j - 4
+        nsd_bf8 pf[NP];
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wv[i] = (uint32_t)from_f<BF16>(st[2 * np][2 * i]).b | ((uint32_t)from_f<BF16>(st[2 * np][2 * i + 1]).b << 16);
+                wv[2 + i] = (uint32_t)from_f<BF16>(st[2 * np + 1][2 * i]).b |
+                            ((uint32_t)from_f<BF16>(st[2 * np + 1][2 * i + 1]).b << 16);
+            }
+            pf[np] = __builtin_bit_cast(nsd_bf8, make_uint4(wv[0], wv[1], wv[2], wv[3]));
+        }
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            nsd_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const BF16 *vp = Vt + (size_t)(dt * 16 + c16) * a.S32 + 4 * g4;
+#pragma unroll
+            for (int np = 0; np < NP; ++np) {
+                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + 32 * np);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(vp + 32 * np + 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[np], __builtin_bit_cast(nsd_bf8, make_uint4(lo.x, lo.y, hi.x, hi.y)),
+                                                              acc, 0, 0, 0);
+            }
+            // acc[reg] = query row r0 + 4 g4 + reg, head dimension 16 dt + c16
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = r0 + 4 * g4 + e;
+                if (rr < R) {
+                    const size_t orow = (size_t)(u * a.B + rr / G) * a.heads + (size_t)h * G + (size_t)(rr % G);
+                    a.po[orow * HD + dt * 16 + c16] = acc[e];
+                }
+            }
+        }
+        if (g4 == 0 && rv) {
+            a.pm[qrow] = mrow;
+            a.pl[qrow] = lrow;
+        }
+    }
+}
+
+template <int HD>
+int launch_ctx_hd(const CtxArgs &a, hipStream_t s)
+{
+    const int R = a.B * (a.heads / a.kvh);
+    const int waves = R >= 64 ? 4 : (R + 15) / 16;
+    const dim3 grid((unsigned)(a.N * a.kvh)), block(64 * waves);
+    switch (a.S32 / 32) {
+    case 1: hipLaunchKernelGGL((nsd_attn_ctx_kernel<1, HD>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((nsd_attn_ctx_kernel<2, HD>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((nsd_attn_ctx_kernel<3, HD>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((nsd_attn_ctx_kernel<4, HD>), grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((nsd_attn_ctx_kernel<5, HD>), grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((nsd_attn_ctx_kernel<6, HD>), grid, block, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((nsd_attn_ctx_kernel<7, HD>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((nsd_attn_ctx_kernel<8, HD>), grid, block, 0, s, a); break;
+    default: return NSD_E_SIZE;
+    }
+    return (int)hipGetLastError();
 }
 
 template <class T, int G>
@@ -444,9 +597,26 @@ extern "C" int nsd_swiglu(const void *gate_up, int64_t rows, int32_t inter, int3
     return (int)hipGetLastError();
 }
 
+extern "C" int nsd_attn_ctx(const void *q, const void *kctx_pad, const void *vctx_t, int32_t N, int32_t B, int32_t heads,
+                            int32_t kvh, int32_t hd, int32_t S, int32_t S32, float scale, float *part_o, float *part_m,
+                            float *part_l, void *stream)
+{
+    if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
+    if (N < 0 || heads < 1 || kvh < 1 || heads % kvh || S < 1 || S32 < S || S32 % 32 || S32 > 256 || (hd != 64 && hd != 128))
+        return NSD_E_SIZE;
+    if (N == 0) return NSD_OK;
+    if (!q || !kctx_pad || !vctx_t || !part_o || !part_m || !part_l) return NSD_E_NULL;
+    CtxArgs a;
+    a.q = (const BF16 *)q; a.kpad = (const BF16 *)kctx_pad; a.vt = (const BF16 *)vctx_t;
+    a.po = part_o; a.pm = part_m; a.pl = part_l;
+    a.N = N; a.B = B; a.heads = heads; a.kvh = kvh; a.S = S; a.S32 = S32; a.scale = scale;
+    return hd == 64 ? launch_ctx_hd<64>(a, (hipStream_t)stream) : launch_ctx_hd<128>(a, (hipStream_t)stream);
+}
+
 extern "C" int nsd_attn_step(const void *q, const void *kctx, const void *vctx, const void *kgen, const void *vgen,
                              const uint8_t *anc, void *out, int32_t N, int32_t B, int32_t heads, int32_t kvh, int32_t hd,
-                             int32_t S, int32_t t, float scale, int32_t dtype, void *stream)
+                             int32_t S, int32_t t, float scale, int32_t dtype, const float *part_o, const float *part_m,
+                             const float *part_l, void *stream)
 {
     if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
     if (N < 0 || heads < 1 || kvh < 1 || heads % kvh || S < 0 || t < 0 || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
@@ -456,8 +626,11 @@ extern "C" int nsd_attn_step(const void *q, const void *kctx, const void *vctx, 
         if (hd < vn || hd > 256 || (hd & (hd - 1))) return NSD_E_SIZE;
     }
     if (N == 0) return NSD_OK;
-    if (!q || !kgen || !vgen || !out || (S > 0 && (!kctx || !vctx)) || (t > 0 && !anc)) return NSD_E_NULL;
+    const bool part = part_o != nullptr;
+    if (part && (!part_m || !part_l)) return NSD_E_NULL;
+    if (!q || !kgen || !vgen || !out || (S > 0 && !part && (!kctx || !vctx)) || (t > 0 && !anc)) return NSD_E_NULL;
     AttnArgs a;
+    a.part_o = part_o; a.part_m = part_m; a.part_l = part_l;
     a.q = q; a.kctx = kctx; a.vctx = vctx; a.kgen = kgen; a.vgen = vgen; a.anc = anc; a.out = out;
     a.N = N; a.B = B; a.heads = heads; a.kvh = kvh; a.hd = hd; a.S = S; a.t = t; a.M = N * B; a.scale = scale;
     return dtype == 0 ? launch_attn<float>(a, (hipStream_t)stream) : launch_attn<BF16>(a, (hipStream_t)stream);

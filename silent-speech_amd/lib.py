@@ -57,7 +57,7 @@ EXPORTS = ["nsd_version", "nsd_strerror", "nsd_hash64", "nsd_tables_create", "ns
            "nsd_ctc_greedy", "nsd_lm_logp", "nsd_rerank_gather", "nsd_log_softmax", "nsd_synth_logits",
            "nsd_decode_synth", "nsd_rerank_lm", "nsd_cond_dist", "nsd_lm_prior_ce", "nsd_lm_prior_ce_grad", "nsd_kv_reorder",
            "nsd_shutdown", "nsd_decode_synth_noalloc", "nsd_ancestors", "nsd_add_rmsnorm", "nsd_rope_kv_append",
-           "nsd_attn_step", "nsd_swiglu"]
+           "nsd_attn_step", "nsd_attn_ctx", "nsd_swiglu"]
 
 _lib = None
 
@@ -97,7 +97,9 @@ def load():
     L.nsd_ancestors.argtypes = [vp, i32, i32, i32, vp, vp]
     L.nsd_add_rmsnorm.argtypes = [vp, vp, vp, C.c_float, i32, i32, i32, vp, vp, vp]
     L.nsd_rope_kv_append.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
-    L.nsd_attn_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp]
+    L.nsd_attn_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp, vp, vp,
+                                vp]
+    L.nsd_attn_ctx.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp]
     L.nsd_swiglu.argtypes = [vp, i64, i32, i32, vp, vp]
     L.nsd_rerank_lm.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
     L.nsd_kv_reorder.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

@@ -126,6 +126,7 @@ def _attn_reference(q, kctx, vctx, kgen, vgen, anc, N, B, S, t, scale):
     (torch.float32, 2, 4, 4, 2, 16, 9, 5), (torch.float32, 1, 1, 1, 1, 4, 0, 0), (torch.float32, 2, 17, 8, 1, 64, 70, 3),
     (torch.bfloat16, 2, 16, 24, 8, 128, 96, 63), (torch.bfloat16, 1, 33, 6, 2, 128, 130, 40),
     (torch.bfloat16, 3, 5, 4, 1, 256, 7, 64), (torch.float32, 2, 3, 3, 3, 32, 64, 0),
+    (torch.bfloat16, 2, 7, 8, 2, 64, 33, 10), (torch.bfloat16, 1, 64, 3, 1, 128, 256, 2), (torch.bfloat16, 3, 1, 2, 2, 64, 1, 0),
 ])
 def test_attention_step_kernel(dtype, N, B, heads, kvh, hd, S, t):
     from silent_speech_amd import lib
@@ -153,11 +154,30 @@ def test_attention_step_kernel(dtype, N, B, heads, kvh, hd, S, t):
     scale = 1.0 / hd ** 0.5
     dq, dk, dv, dkg, dvg = (x.to(dev) for x in (q, kctx if S else torch.zeros(1, dtype=dtype), vctx if S else torch.zeros(1, dtype=dtype), kgen, vgen))
     lib.check(L.nsd_attn_step(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dkg.data_ptr(), dvg.data_ptr(), anc.data_ptr(),
-                              out.data_ptr(), N, B, heads, kvh, hd, S, t, scale, 0 if dtype == torch.float32 else 1, st),
-              "nsd_attn_step")
+                              out.data_ptr(), N, B, heads, kvh, hd, S, t, scale, 0 if dtype == torch.float32 else 1,
+                              None, None, None, st), "nsd_attn_step")
     want = _attn_reference(q, kctx, vctx, kgen, vgen, want_anc, N, B, S, t, scale)
     err = float((out.cpu().double() - want).abs().max())
     assert err < (2e-5 if dtype == torch.float32 else 2e-2), err
+    if dtype == torch.bfloat16 and hd in (64, 128) and 0 < S <= 256:
+        # the context part on the matrix cores, continued by the per-hypothesis kernel
+        S32 = (S + 31) // 32 * 32
+        kpad = torch.zeros(N, kvh, S32, hd, dtype=dtype, device=dev)
+        kpad[:, :, :S] = dk
+        vt = torch.zeros(N, kvh, hd, S32, dtype=dtype, device=dev)
+        vt[:, :, :, :S] = dv.transpose(-1, -2)
+        po = torch.full((M * heads, hd), float("nan"), dtype=torch.float32, device=dev)
+        pm = torch.full((M * heads,), float("nan"), dtype=torch.float32, device=dev)
+        pl = torch.full((M * heads,), float("nan"), dtype=torch.float32, device=dev)
+        lib.check(L.nsd_attn_ctx(dq.data_ptr(), kpad.data_ptr(), vt.data_ptr(), N, B, heads, kvh, hd, S, S32, scale,
+                                 po.data_ptr(), pm.data_ptr(), pl.data_ptr(), st), "nsd_attn_ctx")
+        out2 = torch.zeros_like(out)
+        lib.check(L.nsd_attn_step(dq.data_ptr(), None, None, dkg.data_ptr(), dvg.data_ptr(), anc.data_ptr(),
+                                  out2.data_ptr(), N, B, heads, kvh, hd, S, t, scale, 1, po.data_ptr(), pm.data_ptr(),
+                                  pl.data_ptr(), st), "nsd_attn_step")
+        assert not bool(torch.isnan(po).any()) and not bool(torch.isnan(pl).any())
+        err2 = float((out2.cpu().double() - want).abs().max())
+        assert err2 < 2e-2, err2
 
 
 @pytest.mark.gpu
