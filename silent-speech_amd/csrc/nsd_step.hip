@@ -46,6 +46,11 @@ constexpr uint32_t SEL_NONE = 0xFFFFFFFFu;
 __device__ unsigned long long *g_nsd_stamps = nullptr;
 #define NSD_STAMP(k) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define NSD_STAMP_VALUE(k, v) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 16 + (k)] = (unsigned long long)(v); } while (0)
+#elif defined(NSD_STOP_AT)
+// Diagnostic build only: the kernel ends at one phase boundary, so that instruction counters of builds that end
+// at successive boundaries, launched on the same input, give the instructions of each phase.
+#define NSD_STAMP(k) do { if ((k) == NSD_STOP_AT) return; } while (0)
+#define NSD_STAMP_VALUE(k, v) do { } while (0)
 #else
 #define NSD_STAMP(k) do { } while (0)
 #define NSD_STAMP_VALUE(k, v) do { } while (0)
@@ -69,6 +74,25 @@ struct StepArgs {
     uint32_t     cap;            // candidate buffer entries per utterance
     uint32_t     lds_nodes;      // trie node records every workgroup stages at the front of its LDS (0 = none)
 };
+
+// The kernel's argument block read anew: loads through the returned pointer are not merged with earlier loads of the
+// same arguments, so pointers a phase needs are fetched (one scalar load) where that phase starts instead of being
+// held in scalar registers, or spilled to vector lanes, from the top of the kernel.  StepArgs is the kernel's first
+// parameter, i.e. it sits at offset 0 of the kernel-argument segment.
+using StepArgsK = const __attribute__((address_space(4))) StepArgs;
+NSD_D StepArgsK *fresh_args()
+{
+    StepArgsK *p = (StepArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+NSD_D NsdTables fresh_tables(StepArgsK *k)
+{
+    NsdTables t;
+    __builtin_memcpy(&t, &k->tab, sizeof(t));
+    return t;
+}
 
 // One utterance's LDS region.  Hypothesis fields are interleaved in 104-byte records (one address per
 // hypothesis, fields at constant offsets); the candidate arrays follow at offsets that depend on the beam
@@ -234,14 +258,15 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     }
 
     if (act && (um & NSD_U_DONE)) {
-        if (a.in.score != a.out.score) {
+        StepArgsK *E = fresh_args();
+        if (E->in.score != E->out.score) {
             if (gl < nbeams) {
-                a.out.score[si] = ld_score; a.out.lmsum[si] = ld_G0; a.out.lmsum_e[si] = ld_Ge;
-                a.out.ctx[si] = ld_ctx;     a.out.hist[si] = ld_hist;
-                a.out.ctx_id[si] = ld_ctx_id; a.out.ctxe_id[si] = ld_ctxe_id;
-                a.out.node[si] = ld_node;   a.out.meta[si] = ld_meta;
+                E->out.score[si] = ld_score; E->out.lmsum[si] = ld_G0; E->out.lmsum_e[si] = ld_Ge;
+                E->out.ctx[si] = ld_ctx;     E->out.hist[si] = ld_hist;
+                E->out.ctx_id[si] = ld_ctx_id; E->out.ctxe_id[si] = ld_ctxe_id;
+                E->out.node[si] = ld_node;   E->out.meta[si] = ld_meta;
             }
-            if (gl == 0) a.out.utt[u] = um;
+            if (gl == 0) E->out.utt[u] = um;
         }
         act = false;
     }
@@ -364,6 +389,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // 2 C <= CAP) the n-gram transition of a character or space candidate is left in the unused top of
     // the buffer (entry CAP-1-i for candidate i), where the write phase finds it for the survivors.
     auto score_new = [&](uint32_t from, bool keep) {
+        const NsdTables T = fresh_tables(fresh_args());
         const uint32_t rounds = wave_max(act && C > from ? (C - from + G - 1) / G : 0u);
         for (uint32_t rd = 0; rd < rounds; ++rd) {
             const uint32_t i = from + rd * G + gl;
@@ -398,8 +424,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 double lgn = 0.0;
                 if (use_lm && !is_eos && (keep || !is_sp)) {
                     const uint64_t ctx = L.bCtx(p);
-                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                    s = nsd_lm_advance(a.tab, 1 + glen, ctxe, L.bCtxeId(p), L.bSym(p), L.bLmBase(p), L.bBo(p), tok + 1u);
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(T, ctx, NSD_SPACE + 1u) : ctx;
+                    s = nsd_lm_advance(T, 1 + glen, ctxe, L.bCtxeId(p), L.bSym(p), L.bLmBase(p), L.bBo(p), tok + 1u);
                     lgn = L.bGe(p);
                     if (s.has_int) lgn = lgn + s.lint;
                     if (keep) {
@@ -865,7 +891,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     auto fetch_row = [&](int pass) {
         const int slot = pass * RPP + (gl >> 3);
         if (act && slot < nlive) {
-            const float *row = a.logits + ((size_t)u * B + (int)L.live(slot)) * NSD_V + j * 5;
+            const float *row = fresh_args()->logits + ((size_t)u * B + (int)L.live(slot)) * NSD_V + j * 5;
 #pragma unroll
             for (int k = 0; k < 5; ++k) xn[k] = row[k];
         } else {
@@ -996,6 +1022,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 
     // ---------------- write the surviving hypotheses ----------------
     bool fin = true;
+    StepArgsK *W = fresh_args();                   // output pointers are fetched here, not held from the top
+    const NsdTables WT = fresh_tables(W);
     if (act && gl < nsel) {
         uint32_t mysel = L.sel(gl);
         if (mysel >= C) mysel = 0;                 // only reachable with NaN keys
@@ -1029,7 +1057,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                     Ge = L.cKey()[CAP - 1u - mysel];
                     ctxe_id = L.cInfo()[CAP - 1u - mysel];
                 } else if (use_lm) {
-                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctx, ctx_id, L.bSym(p), L.bLmBase(p),
+                    const NsdLmStep s = nsd_lm_advance(WT, 1 + glen, ctx, ctx_id, L.bSym(p), L.bLmBase(p),
                                                        L.bBo(p), NSD_SPACE + 1u);
                     Ge = s.has_int ? G0 + s.lint : G0;
                     ctxe_id = s.full_new ? s.next_id : NSD_CTX_NONE;
@@ -1038,13 +1066,13 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 node = 0;
             } else {
                 if (use_lm && kept) {
-                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(WT, ctx, NSD_SPACE + 1u) : ctx;
                     G0 = Ge = L.cKey()[CAP - 1u - mysel];
-                    ctx = nsd_ctx_shift(a.tab, ctxe, tok + 1u);
+                    ctx = nsd_ctx_shift(WT, ctxe, tok + 1u);
                     ctx_id = ctxe_id = L.cInfo()[CAP - 1u - mysel];
                 } else if (use_lm) {
-                    const uint64_t ctxe = pend ? nsd_ctx_shift(a.tab, ctx, NSD_SPACE + 1u) : ctx;
-                    const NsdLmStep s = nsd_lm_advance(a.tab, 1 + glen, ctxe, ctxe_id, L.bSym(p), L.bLmBase(p),
+                    const uint64_t ctxe = pend ? nsd_ctx_shift(WT, ctx, NSD_SPACE + 1u) : ctx;
+                    const NsdLmStep s = nsd_lm_advance(WT, 1 + glen, ctxe, ctxe_id, L.bSym(p), L.bLmBase(p),
                                                        L.bBo(p), tok + 1u);
                     G0 = s.has_int ? Ge + s.lint : Ge;
                     Ge = G0;
@@ -1060,11 +1088,11 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         meta = flags | ((uint32_t)glen << 8);
         fin = (flags & NSD_F_FINISHED) != 0;
         const size_t o = (size_t)u * B + gl;
-        a.out.score[o] = score; a.out.lmsum[o] = G0; a.out.lmsum_e[o] = Ge; a.out.ctx[o] = ctx; a.out.hist[o] = hist;
-        a.out.ctx_id[o] = ctx_id; a.out.ctxe_id[o] = ctxe_id;
-        a.out.node[o] = node;   a.out.meta[o] = meta;
-        a.backptr[o] = (uint8_t)p;
-        a.token[o] = out_tok;
+        W->out.score[o] = score; W->out.lmsum[o] = G0; W->out.lmsum_e[o] = Ge; W->out.ctx[o] = ctx; W->out.hist[o] = hist;
+        W->out.ctx_id[o] = ctx_id; W->out.ctxe_id[o] = ctxe_id;
+        W->out.node[o] = node;   W->out.meta[o] = meta;
+        W->backptr[o] = (uint8_t)p;
+        W->token[o] = out_tok;
     }
     const bool all_fin = gballot(!fin) == 0;
     const bool any_err = gballot(err_topk) != 0;
@@ -1072,8 +1100,8 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         uint32_t nu = (uint32_t)nsel | (((um >> NSD_U_STEPS_SHIFT) + 1u) << NSD_U_STEPS_SHIFT) | (um & NSD_U_ERR_TOPK);
         if (all_fin) nu |= NSD_U_DONE;
         if (any_err) nu |= NSD_U_ERR_TOPK;
-        a.out.utt[u] = nu;
-        if (all_fin && a.out.done_count) atomicAdd(a.out.done_count, 1u);
+        W->out.utt[u] = nu;
+        if (all_fin && W->out.done_count) atomicAdd(W->out.done_count, 1u);
     }
     NSD_STAMP(5);
 }
