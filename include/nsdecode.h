@@ -40,6 +40,7 @@ extern "C" {
 #define NSD_MAX_STEPS      128
 #define NSD_MAX_ORDER      10
 #define NSD_MAX_LDS_TRIE_NODES 1024
+#define NSD_MAX_HYPS       (1 << 26)  /* N * B of one nsd_step launch (the kernel indexes hypotheses and logits rows in 32 bits) */
 #define NSD_NODE_DEAD      0xFFFFFFFFu
 #define NSD_KEY_EMPTY      0xFFFFFFFFFFFFFFFFull
 #define NSD_TOKEN_CARRY    0xFFu     /* "no token this step": a finished hypothesis carried over */

@@ -178,10 +178,18 @@ NSD_D void nsd_row_log_softmax5(float (&x)[5])
 {
     // After the distance-1 and distance-2 steps the four lanes of a quad hold the same value, so the
     // mirrored lane (7 - i) of the other quad carries exactly what the lane at distance 4 carries.
-    float m = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), x[4]);
-    m = fmaxf(m, nsd_dpp_xor1(m));
-    m = fmaxf(m, nsd_dpp_xor2(m));
-    m = fmaxf(m, nsd_dpp_half_mirror(m));
+    // Written out: from fmaxf the compiler first re-quiets every operand (v_max x, x, x) and moves the permuted
+    // value through a register of its own, 16 instructions for these five.  NaN operands are ignored as by fmaxf.
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(m) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]));
     nsd_f2 a = {x[0], x[1]}, b = {x[2], x[3]};
     a = a - m;
     b = b - m;

@@ -102,7 +102,7 @@ struct GroupLds {
     uint32_t c_off, s_off, i_off, t_off;       // candidate keys, compaction arrays, candidate info words, total
     uint32_t cap;
     static constexpr uint32_t REC = 104;
-    template <class T> NSD_D T &rec(uint32_t p, uint32_t off) const { return *reinterpret_cast<T *>(base + p * REC + off); }
+    template <class T> NSD_D T &rec(uint32_t p, uint32_t off) const { return *reinterpret_cast<T *>(base + __umul24(p, REC) + off); }   // p < 64: the 24-bit multiply-add is one full-rate instruction
     NSD_D double &bScore(uint32_t p) const { return rec<double>(p, 0); }
     NSD_D double &bG(uint32_t p) const { return rec<double>(p, 8); }
     NSD_D double &bGe(uint32_t p) const { return rec<double>(p, 16); }
@@ -234,7 +234,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // (slots past the current beam count hold stale values, which are never used): one memory round trip
     // instead of two.  Both the early-out below and the step proper consume them.
     const bool slot = act && gl < B;
-    const size_t si = (size_t)u * B + (slot ? gl : 0);
+    const uint32_t si = (uint32_t)u * (uint32_t)B + (uint32_t)(slot ? gl : 0);   // N * B <= NSD_MAX_HYPS: 32-bit indices
     uint32_t um = NSD_U_DONE, ld_meta = 0, ld_node = 0, ld_ctx_id = 0, ld_ctxe_id = 0;
     double ld_score = 0.0, ld_G0 = 0.0, ld_Ge = 0.0;
     uint64_t ld_ctx = 0, ld_hist = 0;
@@ -300,7 +300,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     bool my_live = false;
     if (gl == 0) L.total()[0] = 0;
     if (act && gl < nbeams) {
-        const size_t i = (size_t)u * B + gl;
+        const uint32_t i = (uint32_t)u * (uint32_t)B + (uint32_t)gl;
         const uint32_t meta = ld_meta;
         const uint32_t node = ld_node;
         const uint32_t ctx_id = ld_ctx_id;
@@ -891,7 +891,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     auto fetch_row = [&](int pass) {
         const int slot = pass * RPP + (gl >> 3);
         if (act && slot < nlive) {
-            const float *row = fresh_args()->logits + ((size_t)u * B + (int)L.live(slot)) * NSD_V + j * 5;
+            const float *row = fresh_args()->logits + (((uint32_t)u * (uint32_t)B + L.live(slot)) * (uint32_t)NSD_V + (uint32_t)(j * 5));
 #pragma unroll
             for (int k = 0; k < 5; ++k) xn[k] = row[k];
         } else {
@@ -953,11 +953,41 @@ nsd_step_kernel(StepArgs a, NsdParams P)
 
         // lexicon-allowed characters: the predicate is one compare of the row's mask (0 when the row is
         // not live) with the token's bit, so the ballot is that compare's result itself
+        // One prefix sum over the lanes' candidate counts places all five (a ballot per token costs more,
+        // most of all with several utterances per wave).  The order of candidates in the buffer carries no
+        // meaning: ties are broken by the order field of the info word.
+        {
+            const uint32_t own5 = (uint32_t)((mask & ((1ull << NSD_NBASE) - 1ull)) >> (j * 5)) & 31u;   // this lane's five tokens
+            const uint32_t n = (uint32_t)__popc(own5);
+            uint32_t incl = n;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);         // row_shr:1
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);         // row_shr:2
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);         // row_shr:4
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);         // row_shr:8
+            if (G >= 32) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1, 3
+            if (G == 64) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2, 3
+            uint32_t total;
+            if (G == 64) {
+                total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            } else if (G == 32) {
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                total = g ? t1 : t0;
+            } else {
+                total = (uint32_t)__shfl((int)incl, gshift + G - 1);
+            }
+            uint32_t s = C + incl - n;
+            const uint32_t v0 = (uint32_t)(j * 5);
+            const uint32_t info0 = pack_info(v0, K_CHAR, (VARIANT == NSD_VARIANT_U) ? v0 + 1u : v0, (uint32_t)r);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint32_t v = (uint32_t)(j * 5 + k);
-            const uint64_t vbit = v < NSD_NBASE ? 1ull << v : 0ull;
-            emit((mask & vbit) != 0, x[k], pack_info(v, K_CHAR, (VARIANT == NSD_VARIANT_U) ? v + 1u : v, (uint32_t)r));
+            for (int k = 0; k < 5; ++k) {
+                const bool pred = (own5 & (1u << k)) != 0;
+                if (pred) {
+                    L.cInfo()[s] = info0 + (uint32_t)k * 0x101u;     // token and order both advance by one
+                    reinterpret_cast<float *>(L.cKey())[2 * s] = x[k];
+                }
+                s += pred ? 1u : 0u;
+            }
+            C += total;
         }
         // EOS option (variants U and E): token 38 is element 3 of the row's last lane
         if (VARIANT != NSD_VARIANT_I)
@@ -1087,7 +1117,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
         meta = flags | ((uint32_t)glen << 8);
         fin = (flags & NSD_F_FINISHED) != 0;
-        const size_t o = (size_t)u * B + gl;
+        const uint32_t o = (uint32_t)u * (uint32_t)B + (uint32_t)gl;
         W->out.score[o] = score; W->out.lmsum[o] = G0; W->out.lmsum_e[o] = Ge; W->out.ctx[o] = ctx; W->out.hist[o] = hist;
         W->out.ctx_id[o] = ctx_id; W->out.ctxe_id[o] = ctxe_id;
         W->out.node[o] = node;   W->out.meta[o] = meta;
@@ -1165,7 +1195,7 @@ int nsd_step_with_events(const NsdTables *t, const NsdParams *p, const float *lo
     if (!t || !p) return NSD_E_NULL;
     if (B < 1 || B > NSD_MAX_BEAM) return NSD_E_BEAM;
     if (V != NSD_V) return NSD_E_VOCAB;
-    if (N < 0) return NSD_E_SIZE;
+    if (N < 0 || (long long)N * B > (long long)NSD_MAX_HYPS) return NSD_E_SIZE;
     if (p->variant < NSD_VARIANT_U || p->variant > NSD_VARIANT_E) return NSD_E_VARIANT;
     if (N == 0) return NSD_OK;
     if (!logits || !in || !out || !backptr || !token) return NSD_E_NULL;
