@@ -270,7 +270,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         }
         act = false;
     }
-    if (__ballot(act) == 0) return;               // every utterance of this wave is finished or out of range
+    if (__builtin_amdgcn_ballot_w64(act) == 0) return;               // every utterance of this wave is finished or out of range
     NSD_STAMP(0);
 
     auto gballot = [&](bool pred) -> uint64_t { return (__builtin_amdgcn_ballot_w64(pred) >> gshift) & gmask; };
@@ -602,7 +602,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         // ---- threshold: at most fcap survivors, two per lane ----
         const uint32_t fcap = 2u * (uint32_t)G;
         constexpr int KMAX = 4;                    // keys a lane keeps in registers during the search
-        if (__ballot(want && C > (uint32_t)G) != 0 && chunks <= (uint32_t)KMAX) {
+        if (__builtin_amdgcn_ballot_w64(want && C > (uint32_t)G) != 0 && chunks <= (uint32_t)KMAX) {
             // Runs on registers: lane gl holds candidates gl, gl + G, ...
             const bool in = want && C > (uint32_t)G;
             double kk[KMAX];
@@ -644,7 +644,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             }
             // Beyond fcap survivors: a pivot is broadcast from the lane that owns it and counted with one
             // compare + ballot per held key.
-            for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
+            for (int it = 0; it < 48 && __builtin_amdgcn_ballot_w64(searching) != 0; ++it) {
                 NSD_COUNT(dbg_iters);
                 bool have = false;
                 double pivot = 0.0;
@@ -698,17 +698,17 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             }
             nsd_wave_sync();
             if (ok) { keys = L.sKey(); compacted = true; }
-        } else if (__ballot(want && C > fcap) != 0) {
+        } else if (__builtin_amdgcn_ballot_w64(want && C > fcap) != 0) {
             bool searching = want && C > fcap;
             double lo = -__builtin_inf(), hi = __builtin_inf(), tau = 0.0;
             bool ok = false;
             NSD_COUNT(dbg_slowthr);
-            for (int it = 0; it < 48 && __ballot(searching) != 0; ++it) {
+            for (int it = 0; it < 48 && __builtin_amdgcn_ballot_w64(searching) != 0; ++it) {
                 NSD_COUNT(dbg_iters);
                 // pivot: first key inside (lo, hi), starting at a lane that rotates with the iteration
                 bool have = false;
                 double pivot = 0.0;
-                for (uint32_t ch = 0; ch < chunks && __ballot(searching && !have) != 0; ++ch) {
+                for (uint32_t ch = 0; ch < chunks && __builtin_amdgcn_ballot_w64(searching && !have) != 0; ++ch) {
                     const uint32_t i = ch * G + gl;
                     const bool inb = searching && !have && i < C;
                     const double k = inb ? L.cKey()[i] : 0.0;
@@ -832,7 +832,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         // edge it makes more claimants than places
         const bool hole = want && gl < nsel && L.sel(gl) == SEL_NONE;
         const bool redo = want && (full_scan || claimed != (uint32_t)nsel || gballot(hole) != 0);
-        if (__ballot(redo) != 0) {
+        if (__builtin_amdgcn_ballot_w64(redo) != 0) {
             NSD_COUNT(dbg_redo);
             if (redo && gl < B) L.sel(gl) = SEL_NONE;
             nsd_wave_sync();
@@ -880,7 +880,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // finished hypotheses compete unchanged (ns_utils.py:222-224); they are scored with the first pass
     emit(act && gl < nbeams && !my_live, 0.0f, pack_info(0x3f, K_CARRY, 0, (uint32_t)gl));
     // when everything the step can emit fits the buffer (the usual case) no pass needs an overflow check
-    const bool may_overflow = __ballot(act && L.total()[0] > CAP) != 0;
+    const bool may_overflow = __builtin_amdgcn_ballot_w64(act && L.total()[0] > CAP) != 0;
 
     // ---------------- passes: log-softmax, candidates, scores ----------------
     const int j = lane & 7;
@@ -926,16 +926,16 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             for (int off = 8; off < G; off <<= 1) add += __shfl_xor(add, off);
             add = __shfl(add, gshift);
             bool over = act && C + add > CAP;
-            if (__ballot(over && C > (uint32_t)G) != 0) {
+            if (__builtin_amdgcn_ballot_w64(over && C > (uint32_t)G) != 0) {
                 nsd_wave_sync();
                 bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
                 over = act && C + add > CAP;
             }
-            if (__ballot(over) != 0) {
+            if (__builtin_amdgcn_ballot_w64(over) != 0) {
                 NSD_TIC();
                 // score_new covers every group of the wave; when it does not run, the groups that are not
                 // over keep their unscored tail
-                if (__ballot(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
+                if (__builtin_amdgcn_ballot_w64(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
                 NSD_TOC(dbg_t_score);
                 NSD_TIC();
                 prune(over);
@@ -995,7 +995,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                  pack_info(NSD_EOS, K_EOS, (VARIANT == NSD_VARIANT_U) ? 0u : 40u, (uint32_t)r));
 
         // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
-        if (__ballot(fb) != 0) {
+        if (__builtin_amdgcn_ballot_w64(fb) != 0) {
             float *rb = L.rowbuf() + (gl >> 3) * NSD_V;
 #pragma unroll
             for (int k = 0; k < 5; ++k) rb[j * 5 + k] = x[k];
@@ -1023,7 +1023,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // it saves; it is repeated only while the buffer still exceeds two rounds and the last sweep removed something)
     {
         bool again = act && C > 2u * (uint32_t)G;
-        for (int it = 0; it < 3 && __ballot(again) != 0; ++it) {
+        for (int it = 0; it < 3 && __builtin_amdgcn_ballot_w64(again) != 0; ++it) {
             const uint32_t before = C;
             bound_prune(again);
             again = again && C > 2u * (uint32_t)G && C < before;
