@@ -225,7 +225,8 @@ int nsd_state_init(const NsdTables *t, const NsdBeamState *st, int32_t N, int32_
  *   backptr  device [N*B] u8: rank of the parent hypothesis   (this step's slice)
  *   token    device [N*B] u8: appended token or NSD_TOKEN_CARRY (this step's slice)
  *   mask_dbg device [N*B] u64 or NULL: lexicon mask of each live parent
- * Utterances already NSD_U_DONE are left untouched. */
+ * Utterances already NSD_U_DONE are left untouched.  N * B above NSD_MAX_HYPS
+ * is refused with NSD_E_SIZE before anything is enqueued (split the batch). */
 int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
              const NsdBeamState *in, const NsdBeamState *out,
              uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,

@@ -284,6 +284,16 @@ def test_edge_shapes(dev):
         NSDecoder(tables, 65, 8)
     with pytest.raises(ValueError):
         NSDecoder(tables, 4, 129)
+    # nsd_step indexes hypotheses and logits rows in 32 bits: a launch with N * B beyond NSD_MAX_HYPS is refused
+    # before anything is enqueued (the pointers are never used)
+    import ctypes as C
+    from silent_speech_amd import lib as _lib
+    L = _lib.load()
+    small = dec.workspace(2)
+    too_many = (1 << 26) // 64 + 1
+    rc = L.nsd_step(tables.handle, C.byref(dec.params), small.logits.data_ptr(), C.byref(small.ptrs), C.byref(small.ptrs),
+                    small.backptr.data_ptr(), small.token.data_ptr(), None, too_many, 64, 40, None)
+    assert rc == -7 and b"size" in L.nsd_strerror(rc).lower()
 
 
 def test_ctc_greedy(dev):
