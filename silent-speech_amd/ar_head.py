@@ -5,7 +5,8 @@ The reference re-runs the frozen decoder-only LLM over the whole sequence [conte
 hypothesis at a time and keeps the last position (inference_emg_llm.py:427-429).  Here the context (soft prompt,
 prompt embeddings, EMG adapter output) is run once per utterance and its keys/values are shared by the
 utterance's hypotheses; every step then feeds ONE new token per hypothesis, after re-ordering the cache of the
-generated positions by the scorer's back-pointers.  The dense contractions stay torch / hipBLASLt; this module
+generated positions by the scorer's back-pointers.  `teacher_logits` scores whole candidate transcripts against the
+same cached contexts in one causal pass (the `ar_logprob` of eval_ar.py:574-588).  The dense contractions stay torch / hipBLASLt; this module
 is plumbing around them (no hand-written kernels), and its output feeds `NSDecoder.step`.
 
 Architecture = transformers' LlamaModel (pre-norm, RMSNorm, rotary embedding in the rotate-half form, grouped
@@ -216,6 +217,48 @@ class TorchLlamaStep:
             x = x + self._mlp(l, _rms(x, self.w[f"{l}.ln2"], d.rms_eps))
         x = _rms(x, self.w["norm"], d.rms_eps)
         self.t = t + 1
+        return F.linear(x, self.w["lm_head.w"], self.w["lm_head.b"]).float()
+
+    # ------------------------------------------------------------------ teacher-forced scoring (rerank E)
+    @torch.no_grad()
+    def teacher_logits(self, seq: torch.Tensor, lens: torch.Tensor, utt: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Logits after every prefix of M token sequences, against the contexts cached by `encode_context`:
+        row i of sequence m is what the reference's `step_fn(seq[m, :i+1])` returns, which its `ar_logprob`
+        (eval_ar.py:574-588) obtains from one whole-sequence forward per prefix.  Here it is ONE causal pass over
+        [context ; char_embed(seq[:, :-1])] per sequence, the context keys / values taken from the cache.
+
+        seq [M, L] integer (BOS first, padded with any valid id), lens [M] (only documents what the caller may read:
+        rows at or past lens[m]-1 come from padding); utt [M] = index of the utterance whose context sequence m
+        continues (default m mod N: the AR candidates of all utterances, then the CTC candidates, as
+        `decoder.transcribe_batch_joint` lays them out).  Returns float32 [M, L-1, vocab] — the `teacher_logits`
+        callable that function asks for."""
+        d, S, N = self.d, self.S, self.N
+        if N == 0:
+            raise ValueError("encode_context has not run")
+        seq = seq.to(self.device).long()
+        M, L = seq.shape
+        if L < 2:
+            return torch.zeros(M, 0, d.vocab, dtype=torch.float32, device=self.device)
+        if utt is None:
+            utt = torch.arange(M, device=self.device) % N
+        utt = utt.to(self.device).long()
+        L1 = L - 1
+        x = F.embedding(seq[:, :L1], self.w["char_embed"])               # [M, L1, hidden]
+        cos, sin = self._cos_sin(S + torch.arange(L1, device=self.device))
+        cos, sin = cos[None, :, None, :], sin[None, :, None, :]
+        # new position i sees the whole context and new positions <= i
+        mask = torch.cat((torch.ones(L1, S, dtype=torch.bool, device=self.device),
+                          torch.ones(L1, L1, dtype=torch.bool, device=self.device).tril()), dim=1)
+        for l in range(d.layers):
+            h = _rms(x, self.w[f"{l}.ln1"], d.rms_eps)
+            q, k, v = self._split_qkv(F.linear(h, self.w[f"{l}.qkv"]))   # [M, L1, heads, hd]
+            q = _rope(q, cos, sin).transpose(1, 2)
+            k = torch.cat((self.kp[l].index_select(0, utt), _rope(k, cos, sin).transpose(1, 2)), dim=2)
+            v = torch.cat((self.vp[l].index_select(0, utt), v.transpose(1, 2)), dim=2)
+            a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, enable_gqa=True)
+            x = x + F.linear(a.transpose(1, 2).flatten(-2), self.w[f"{l}.o"])
+            x = x + self._mlp(l, _rms(x, self.w[f"{l}.ln2"], d.rms_eps))
+        x = _rms(x, self.w["norm"], d.rms_eps)
         return F.linear(x, self.w["lm_head.w"], self.w["lm_head.b"]).float()
 
     # ------------------------------------------------------------------ glue for NSDecoder.decode_batch

@@ -72,6 +72,42 @@ def test_backptr_form_on_cpu():
     assert _run("cpu", use_backptr=True) < 2e-4
 
 
+def _teacher(device):
+    """teacher_logits against the reference's ar_logprob formulation (eval_ar.py:574-588): one whole-sequence
+    forward per prefix, last position."""
+    from silent_speech_amd.ar_head import TorchLlamaStep
+    llm, char_embed, lm_head = _reference_setup()
+    N, S = 3, 7
+    torch.manual_seed(3)
+    context = torch.randn(N, S, 64) * 0.5
+    head = TorchLlamaStep.from_hf(llm, char_embed.weight.data, lm_head.weight.data, lm_head.bias.data,
+                                  dtype=torch.float32, device=device)
+    head.encode_context(context, beam=2, max_new_tokens=4)
+    rs = np.random.RandomState(4)
+    lens = [6, 2, 9, 4, 5, 3]                                  # 2N sequences: utterance = m mod N
+    L = max(lens)
+    seq = np.full((len(lens), L), 36, np.int64)
+    for m, n in enumerate(lens):
+        seq[m, :n] = [37] + list(rs.randint(0, 37, n - 2)) + [38]
+    got = head.teacher_logits(torch.from_numpy(seq).to(device), torch.tensor(lens, device=device)).cpu()
+    assert got.shape == (len(lens), L - 1, 40)
+    worst = 0.0
+    for m, n in enumerate(lens):
+        for i in range(n - 1):
+            want = _reference_step(llm, char_embed, lm_head, context[m % N:m % N + 1], [int(t) for t in seq[m, :i + 1]])
+            worst = max(worst, float((got[m, i] - want).abs().max()))
+    return worst
+
+
+def test_teacher_forced_logits_match_one_forward_per_prefix_cpu():
+    assert _teacher("cpu") < 2e-4
+
+
+@pytest.mark.gpu
+def test_teacher_forced_logits_match_one_forward_per_prefix_gpu():
+    assert _teacher("cuda") < 2e-4
+
+
 @pytest.mark.gpu
 def test_kv_reorder_equals_index_select():
     """nsd_kv_reorder against torch.index_select, bit for bit, bf16 and fp32 rows, partial position ranges."""
@@ -203,3 +239,57 @@ def test_hip_step_equals_torch_step_bf16():
         assert float((la - lb).abs().max()) < 0.04 * max(scale, 1.0), t
         bp = torch.from_numpy(rs.randint(0, B, N * B).astype(np.uint8)).to(dev)
         tok = torch.from_numpy(rs.randint(0, 37, N * B)).to(dev)
+
+
+@pytest.mark.gpu
+def test_joint_rerank_end_to_end_through_the_ar_head():
+    """eval_ar.py:503-596 with a real (small, random-weight) decoder-only model behind step_fn: variant E beam decode
+    through the KV-cached HIP step, CTC proposal, post-processing, then the joint choice with `ar_logprob` from ONE
+    teacher-forced pass (`teacher_logits`).  Expected values: the restatement of that tail with step_fn = one
+    whole-sequence transformers forward per prefix, as the reference computes it (fp32 on both sides: scores within
+    5e-3, the choice identical wherever the two scores are further apart than 2e-2)."""
+    from oracle import ns_oracle as O, synth
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.ar_head import HipLlamaStep
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder, transcribe_batch_joint
+    dev = torch.device("cuda", 0)
+    llm, char_embed, lm_head = _reference_setup(5)
+    words = synth.make_lexicon(60, 3, max_len=6)
+    lm = O.NgramLM(3, floor_vsz=False).fit(synth.make_sentences(words, 2000, 1))
+    tables = DeviceTables.from_words(words, lm)
+    trie = O.build_trie(words)
+    TT = O.TextTransformLike
+    N, B, S, T, beta = 5, 4, 6, 14, 0.3
+    torch.manual_seed(6)
+    context = torch.randn(N, S, 64) * 0.5
+    with torch.no_grad():
+        lm_head.weight.mul_(30.0)                                     # logits of order 1, so that the beam has preferences
+    head = HipLlamaStep.from_hf(llm, char_embed.weight.data, lm_head.weight.data, lm_head.bias.data,
+                                dtype=torch.float32, device=dev)
+    head.encode_context(context, beam=B, max_new_tokens=T)
+    dec = NSDecoder(tables, B, T, variant="E", lm_weight=beta, oov_penalty=1.0, word_bonus=0.35, min_len_for_eos=3)
+    ar_ids, ar_len, _ = dec.decode_batch(head.step_fn_batched(), N, needs_ids=False, check_every=0)
+    rng = np.random.RandomState(7)
+    ctc_targets = synth.make_sentences(words, N, 9, 1, 2)
+    Tp = 60
+    x = rng.randn(N, Tp, 40).astype(np.float32)
+    for u, t in enumerate(ctc_targets):
+        f = 0
+        for tok in synth.text_to_tokens(t)[: Tp // 3]:
+            x[u, f:f + 2, tok] += 8.0; x[u, f + 2, 39] += 8.0; f += 3
+        x[u, f:, 39] += 8.0
+    final, scores = transcribe_batch_joint(TextTransform, ar_ids, ar_len, tables, trie, words,
+                                           torch.from_numpy(x).to(dev), head.teacher_logits, beta)
+    ar_np, al = ar_ids.cpu().numpy(), ar_len.cpu().numpy()
+    checked = 0
+    for u in range(N):
+        hyp_ar = O.postprocess(O.ids_to_text(TT, ar_np[u, :al[u]].tolist()), trie, words)
+        hyp_ctc = O.postprocess(O.ctc_hypothesis(x[u], TT), trie, words)
+        step_fn = lambda ids, u=u: _reference_step(llm, char_embed, lm_head, context[u:u + 1], ids).unsqueeze(0)   # noqa: E731
+        ref = [O.ar_logprob(s, step_fn, TT, O.lsm_torch) + beta * float(lm.logp(s)) for s in (hyp_ar, hyp_ctc)]
+        for c in (0, 1):
+            assert abs(scores[u, c] - ref[c]) <= 5e-3 * max(1.0, abs(ref[c]) / 10), (u, c, scores[u], ref)
+        if abs(ref[0] - ref[1]) > 2e-2:
+            assert final[u] == (hyp_ctc if ref[1] > ref[0] else hyp_ar), (u, ref)
+            checked += 1
+    assert checked > 0
