@@ -391,7 +391,7 @@ struct CtxArgs {
 };
 
 template <int NP, int HD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 nsd_attn_ctx_kernel(CtxArgs a)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, waves = blockDim.x >> 6;
@@ -421,6 +421,25 @@ nsd_attn_ctx_kernel(CtxArgs a)
                     __builtin_bit_cast(nsd_bf8, *reinterpret_cast<const uint4 *>(kp + 32 * kc)), qf[kc], acc, 0, 0, 0);
             st[nt] = acc;
         }
+        // The value fragments of the first DTB head-dimension tiles are requested here, before the scores are
+        // reduced, so that their round trip runs under the softmax (one round trip per tile otherwise); the launch
+        // has few waves (1.5 per SIMD at 64 utterances x 8 kv heads) and may use the registers of those that are
+        // not there.  Splitting the head dimension over more workgroups was measured and is slower (the repeated
+        // key reads cost more than the extra waves bring: 18.9 -> 22.8 -> 33.4 us for 1 / 2 / 4 workgroups).
+        constexpr int DTN = HD / 16, DTB = NP <= 4 ? DTN : 4;
+        uint2 vlo[DTB][NP], vhi[DTB][NP];
+        auto fetch_v = [&](int dt0) {
+#pragma unroll
+            for (int d = 0; d < DTB; ++d) {
+                const BF16 *vp = Vt + (size_t)((dt0 + d) * 16 + c16) * a.S32 + 4 * g4;
+#pragma unroll
+                for (int np = 0; np < NP; ++np) {
+                    vlo[d][np] = *reinterpret_cast<const uint2 *>(vp + 32 * np);
+                    vhi[d][np] = *reinterpret_cast<const uint2 *>(vp + 32 * np + 16);
+                }
+            }
+        };
+        fetch_v(0);
         float mrow = -__builtin_inff();
 #pragma unroll
         for (int nt = 0; nt < 2 * NP; ++nt) {
@@ -460,23 +479,25 @@ nsd_attn_ctx_kernel(CtxArgs a)
             pf[np] = __builtin_bit_cast(nsd_bf8, make_uint4(wv[0], wv[1], wv[2], wv[3]));
         }
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
-            nsd_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            const BF16 *vp = Vt + (size_t)(dt * 16 + c16) * a.S32 + 4 * g4;
+        for (int dt0 = 0; dt0 < DTN; dt0 += DTB) {
+            if (dt0) fetch_v(dt0);
 #pragma unroll
-            for (int np = 0; np < NP; ++np) {
-                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + 32 * np);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(vp + 32 * np + 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[np], __builtin_bit_cast(nsd_bf8, make_uint4(lo.x, lo.y, hi.x, hi.y)),
-                                                              acc, 0, 0, 0);
-            }
-            // acc[reg] = query row r0 + 4 g4 + reg, head dimension 16 dt + c16
+            for (int d = 0; d < DTB; ++d) {
+                const int dt = dt0 + d;
+                nsd_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = r0 + 4 * g4 + e;
-                if (rr < R) {
-                    const size_t orow = (size_t)(u * a.B + rr / G) * a.heads + (size_t)h * G + (size_t)(rr % G);
-                    a.po[orow * HD + dt * 16 + c16] = acc[e];
+                for (int np = 0; np < NP; ++np)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        pf[np], __builtin_bit_cast(nsd_bf8, make_uint4(vlo[d][np].x, vlo[d][np].y, vhi[d][np].x, vhi[d][np].y)),
+                        acc, 0, 0, 0);
+                // acc[reg] = query row r0 + 4 g4 + reg, head dimension 16 dt + c16
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = r0 + 4 * g4 + e;
+                    if (rr < R) {
+                        const size_t orow = (size_t)(u * a.B + rr / G) * a.heads + (size_t)h * G + (size_t)(rr % G);
+                        a.po[orow * HD + dt * 16 + c16] = acc[e];
+                    }
                 }
             }
         }
