@@ -143,6 +143,71 @@ nsd_add_rmsnorm_kernel(const T *x, const T *delta, const T *w, float eps, int ro
     }
 }
 
+// The same for a row that fits the registers of one workgroup: one workgroup of W waves per row, every lane holds NV
+// 16-byte pieces of it from the first read to the last write (the row is read once), the sum of squares crosses the
+// waves through LDS.  A decode step has about a thousand rows: one wave per row leaves three quarters of the wave
+// slots empty and each wave with a long dependent loop.
+template <class T, int NV>
+__global__ void __launch_bounds__(1024)
+nsd_add_rmsnorm_row_kernel(const T *x, const T *delta, const T *w, float eps, int hidden, T *x_out, T *h)
+{
+    constexpr int VN = Vec16<T>::N;
+    __shared__ float part[16];
+    const int row = blockIdx.x, nvec = hidden / VN;
+    const T *xr = x + (size_t)row * hidden;
+    const T *dr = delta ? delta + (size_t)row * hidden : nullptr;
+    float v[NV][8];
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = (int)threadIdx.x + k * (int)blockDim.x;
+        if (i < nvec) {
+            Vec16<T>::load(xr + (size_t)i * VN, v[k]);
+            if (dr) {
+                float d[8];
+                Vec16<T>::load(dr + (size_t)i * VN, d);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) v[k][e] = to_f(from_f<T>(v[k][e] + d[e]));   // the sum is stored in the element type
+                Store16<T>::store(x_out + (size_t)row * hidden + (size_t)i * VN, v[k]);
+            }
+#pragma unroll
+            for (int e = 0; e < VN; ++e) ss += v[k][e] * v[k][e];
+        }
+    }
+    ss = wave_sum_f(ss);
+    const int waves = (int)blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int q = 0; q < waves; ++q) tot += part[q];
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = (int)threadIdx.x + k * (int)blockDim.x;
+        if (i < nvec) {
+            float g[8];
+            Vec16<T>::load(w + (size_t)i * VN, g);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[k][e] = g[e] * to_f(from_f<T>(v[k][e] * inv));
+            Store16<T>::store(h + (size_t)row * hidden + (size_t)i * VN, v[k]);
+        }
+    }
+}
+
+template <class T>
+void launch_add_rmsnorm(const T *x, const T *delta, const T *w, float eps, int rows, int hidden, T *x_out, T *h, hipStream_t s)
+{
+    constexpr int VN = Vec16<T>::N, NV = 2;
+    const int nvec = hidden / VN;
+    const int waves = (nvec + 64 * NV - 1) / (64 * NV);
+    if (waves <= 16)
+        hipLaunchKernelGGL((nsd_add_rmsnorm_row_kernel<T, NV>), dim3((unsigned)rows), dim3(64 * waves), 0, s,
+                           x, delta, w, eps, hidden, x_out, h);
+    else
+        hipLaunchKernelGGL(nsd_add_rmsnorm_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                           x, delta, w, eps, rows, hidden, x_out, h);
+}
+
 // ---------------------------------------------------------------------
 // rotary embedding (rotate-half form) of q and k; k and v go to the step's slab of the generated cache
 // ---------------------------------------------------------------------
@@ -172,6 +237,42 @@ nsd_rope_kv_append_kernel(const T *qkv, const float *cs, const float *sn, int M,
     T *dst = head < heads ? q_out + ((size_t)m * heads + head) * hd : k_out + ((size_t)m * kvh + (head - heads)) * hd;
     dst[i] = from_f<T>(o1);
     dst[i + half] = from_f<T>(o2);
+}
+
+// The same with 16-byte pieces: a thread takes VN consecutive elements of the first half of a head and the VN
+// elements they are rotated with (hd / 2 a multiple of VN, rows 16-byte aligned: checked by the launcher).
+template <class T>
+__global__ void __launch_bounds__(256)
+nsd_rope_kv_append_vec_kernel(const T *qkv, const float *cs, const float *sn, int M, int heads, int kvh, int hd,
+                              T *q_out, T *k_out, T *v_out)
+{
+    constexpr int VN = Vec16<T>::N;
+    const int half = hd >> 1, hv = half / VN;
+    const int per_row = (heads + 2 * kvh) * hv;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)M * per_row) return;
+    const int m = (int)(gid / per_row), rem = (int)(gid % per_row);
+    const int head = rem / hv, i = (rem % hv) * VN;
+    const T *src = qkv + ((size_t)m * (heads + 2 * kvh) + head) * hd;
+    float x1[8], x2[8];
+    Vec16<T>::load(src + i, x1);
+    Vec16<T>::load(src + i + half, x2);
+    T *dst;
+    if (head >= heads + kvh) {                                   // value rows are copied
+        dst = v_out + ((size_t)m * kvh + (head - heads - kvh)) * hd;
+    } else {
+        dst = head < heads ? q_out + ((size_t)m * heads + head) * hd : k_out + ((size_t)m * kvh + (head - heads)) * hd;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            // x * cos + rotate_half(x) * sin, each product rounded before the sum
+            const float a1 = x1[e] * cs[i + e], b1 = x2[e] * sn[i + e];
+            const float a2 = x2[e] * cs[i + e + half], b2 = x1[e] * sn[i + e + half];
+            x1[e] = a1 - b1;
+            x2[e] = a2 + b2;
+        }
+    }
+    Store16<T>::store(dst + i, x1);
+    Store16<T>::store(dst + i + half, x2);
 }
 
 template <class T>
@@ -573,13 +674,12 @@ extern "C" int nsd_add_rmsnorm(const void *x, const void *delta, const void *w, 
     if (rows < 0 || hidden < 1 || (dtype != 0 && dtype != 1) || hidden % (dtype ? 8 : 4)) return NSD_E_SIZE;
     if (rows == 0) return NSD_OK;
     if (!x || !w || !h || (delta && !x_out)) return NSD_E_NULL;
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (dtype == 0)
-        hipLaunchKernelGGL(nsd_add_rmsnorm_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)x,
-                           (const float *)delta, (const float *)w, eps, rows, hidden, (float *)x_out, (float *)h);
+        launch_add_rmsnorm<float>((const float *)x, (const float *)delta, (const float *)w, eps, rows, hidden,
+                                  (float *)x_out, (float *)h, (hipStream_t)stream);
     else
-        hipLaunchKernelGGL(nsd_add_rmsnorm_kernel<BF16>, grid, block, 0, (hipStream_t)stream, (const BF16 *)x,
-                           (const BF16 *)delta, (const BF16 *)w, eps, rows, hidden, (BF16 *)x_out, (BF16 *)h);
+        launch_add_rmsnorm<BF16>((const BF16 *)x, (const BF16 *)delta, (const BF16 *)w, eps, rows, hidden,
+                                 (BF16 *)x_out, (BF16 *)h, (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
@@ -590,6 +690,19 @@ extern "C" int nsd_rope_kv_append(const void *qkv, const float *cos_t, const flo
     if (M < 0 || heads < 1 || kvh < 1 || hd < 2 || (hd & 1) || (dtype != 0 && dtype != 1)) return NSD_E_SIZE;
     if (M == 0) return NSD_OK;
     if (!qkv || !cos_t || !sin_t || !q_out || !k_out || !v_out) return NSD_E_NULL;
+    const int vn = dtype ? 8 : 4;
+    const bool aligned = ((((uintptr_t)qkv) | ((uintptr_t)q_out) | ((uintptr_t)k_out) | ((uintptr_t)v_out)) & 15u) == 0;
+    if ((hd / 2) % vn == 0 && aligned) {
+        const long long n = (long long)M * (heads + 2 * kvh) * (hd / 2 / vn);
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        if (dtype == 0)
+            hipLaunchKernelGGL(nsd_rope_kv_append_vec_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)qkv,
+                               cos_t, sin_t, M, heads, kvh, hd, (float *)q_out, (float *)k_out, (float *)v_out);
+        else
+            hipLaunchKernelGGL(nsd_rope_kv_append_vec_kernel<BF16>, grid, block, 0, (hipStream_t)stream, (const BF16 *)qkv,
+                               cos_t, sin_t, M, heads, kvh, hd, (BF16 *)q_out, (BF16 *)k_out, (BF16 *)v_out);
+        return (int)hipGetLastError();
+    }
     const long long n = (long long)M * (heads + 2 * kvh) * (hd / 2);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dtype == 0)

@@ -293,3 +293,62 @@ def test_joint_rerank_end_to_end_through_the_ar_head():
             assert final[u] == (hyp_ctc if ref[1] > ref[0] else hyp_ar), (u, ref)
             checked += 1
     assert checked > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,hidden,rows,with_delta", [
+    (torch.float32, 64, 7, True), (torch.float32, 3072, 33, False), (torch.bfloat16, 3072, 130, True),
+    (torch.bfloat16, 8192, 9, True), (torch.bfloat16, 17408, 5, True), (torch.float32, 8200, 3, True)])
+def test_add_rmsnorm_kernel(dtype, hidden, rows, with_delta):
+    """nsd_add_rmsnorm (residual add + RMSNorm; one workgroup per row, or one wave per row beyond 16 waves) against
+    torch: the sum is stored in the element type, the norm is taken of the stored sum in fp32."""
+    import ctypes as C
+    from silent_speech_amd import lib as _lib
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(hidden + rows)
+    x = (torch.randn(rows, hidden, generator=g, device=dev) * 0.7).to(dtype)
+    d = (torch.randn(rows, hidden, generator=g, device=dev) * 0.3).to(dtype) if with_delta else None
+    w = (1.0 + 0.1 * torch.randn(hidden, generator=g, device=dev)).to(dtype)
+    xo, h = torch.empty_like(x), torch.empty_like(x)
+    rc = L.nsd_add_rmsnorm(x.data_ptr(), d.data_ptr() if with_delta else None, w.data_ptr(), 1e-5, rows, hidden,
+                           0 if dtype == torch.float32 else 1, xo.data_ptr() if with_delta else None, h.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    s = (x.float() + d.float()).to(dtype) if with_delta else x
+    sf = s.float()
+    want = w.float() * (sf * torch.rsqrt(sf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype).float()
+    if with_delta:
+        assert torch.equal(xo, s)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((h.float() - want).abs().max()) <= tol * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,heads,kvh,hd,M", [
+    (torch.float32, 4, 2, 16, 5), (torch.float32, 3, 1, 20, 4), (torch.bfloat16, 24, 8, 128, 37),
+    (torch.bfloat16, 4, 4, 64, 9), (torch.bfloat16, 2, 1, 24, 3)])
+def test_rope_kv_append_kernel(dtype, heads, kvh, hd, M):
+    """nsd_rope_kv_append (16-byte pieces when hd / 2 allows, element pairs otherwise) against the rotate-half form in
+    torch: q and k rotated, v copied, each into its own buffer."""
+    from silent_speech_amd import lib as _lib
+    from silent_speech_amd.ar_head import _rope
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(hd + M)
+    qkv = torch.randn(M, heads + 2 * kvh, hd, generator=g, device=dev).to(dtype)
+    ang = torch.rand(hd // 2, generator=g, device=dev) * 6.0
+    ang = torch.cat((ang, ang))
+    cos, sin = ang.cos().to(dtype).float().contiguous(), ang.sin().to(dtype).float().contiguous()
+    q = torch.empty(M, heads, hd, dtype=dtype, device=dev)
+    k = torch.empty(M, kvh, hd, dtype=dtype, device=dev)
+    v = torch.empty(M, kvh, hd, dtype=dtype, device=dev)
+    rc = L.nsd_rope_kv_append(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), M, heads, kvh, hd,
+                              0 if dtype == torch.float32 else 1, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    want = _rope(qkv[:, :heads + kvh], cos.to(dtype), sin.to(dtype))
+    tol = 1e-6 if dtype == torch.float32 else 1.6e-2
+    assert float((q.float() - want[:, :heads].float()).abs().max()) <= tol
+    assert float((k.float() - want[:, heads:].float()).abs().max()) <= tol
+    assert torch.equal(v, qkv[:, heads + kvh:])
