@@ -34,17 +34,16 @@ template <> NSD_D BF16 from_f<BF16>(float v)
 template <class T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int N = 4;
-    NSD_D static void load(const float *p, float (&o)[8])
+    NSD_D static void unpack(const uint4 &v, float (&o)[8])
     {
-        const float4 v = *reinterpret_cast<const float4 *>(p);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
     }
+    NSD_D static void load(const float *p, float (&o)[8]) { unpack(*reinterpret_cast<const uint4 *>(p), o); }
 };
 template <> struct Vec16<BF16> {
     static constexpr int N = 8;
-    NSD_D static void load(const BF16 *p, float (&o)[8])
+    NSD_D static void unpack(const uint4 &v, float (&o)[8])
     {
-        const uint4 v = *reinterpret_cast<const uint4 *>(p);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -52,19 +51,33 @@ template <> struct Vec16<BF16> {
             o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
+    NSD_D static void load(const BF16 *p, float (&o)[8]) { unpack(*reinterpret_cast<const uint4 *>(p), o); }
 };
 
+// Wave-wide maximum / sum, the same value in every lane.  Inside a row of 16 lanes the butterfly runs on DPP register
+// moves (after the distance-1 and -2 steps a quad is uniform, so the mirrored lane of the other quad / half carries
+// what the lane at distance 4 / 8 carries); the four row results meet through scalar registers.  No LDS-crossbar
+// permutes: they cost an address, an LDS instruction and its latency per step.
+NSD_D float nsd_dpp_row_mirror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+}
+NSD_D float row_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 NSD_D float wave_max_f(float v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    return v;
+    v = fmaxf(v, nsd_dpp_xor1(v));
+    v = fmaxf(v, nsd_dpp_xor2(v));
+    v = fmaxf(v, nsd_dpp_half_mirror(v));
+    v = fmaxf(v, nsd_dpp_row_mirror(v));
+    return fmaxf(fmaxf(row_lane(v, 0), row_lane(v, 16)), fmaxf(row_lane(v, 32), row_lane(v, 48)));
 }
 NSD_D float wave_sum_f(float v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d);
-    return v;
+    v = v + nsd_dpp_xor1(v);
+    v = v + nsd_dpp_xor2(v);
+    v = v + nsd_dpp_half_mirror(v);
+    v = v + nsd_dpp_row_mirror(v);
+    return (row_lane(v, 0) + row_lane(v, 16)) + (row_lane(v, 32) + row_lane(v, 48));
 }
 
 // ---------------------------------------------------------------------
@@ -367,7 +380,8 @@ nsd_attn_step_kernel(AttnArgs a)
     float *ps = reinterpret_cast<float *>(smem + (size_t)w * per_wave + q_bytes);   // [G][64] softmax numerators
     const T **vrow = reinterpret_cast<const T **>(ps + G * 64);                // [64] value row of each position
     const T *q = static_cast<const T *>(a.q) + ((size_t)m * a.heads + (size_t)h * G) * hd;
-    for (int i = lane; i < G * hd; i += 64) qs[i] = q[i];
+    for (int i = lane; i < G * hd / VN; i += 64)               // 16-byte pieces (hd is a multiple of VN)
+        reinterpret_cast<uint4 *>(qs)[i] = reinterpret_cast<const uint4 *>(q)[i];
     nsd_wave_sync();
 
     // value sum: LP lanes share a position (16 bytes of the row each), 64 / LP positions advance together
@@ -439,6 +453,8 @@ nsd_attn_step_kernel(AttnArgs a)
         }
         nsd_wave_sync();
         const int n = L - c0 < 64 ? L - c0 : 64;
+        // (requesting the first eight value pieces before the dot products, to take their round trip off the end of
+        // the chunk, costs registers and with them resident waves: 33.9 -> 53.6 us per launch, not kept)
 #pragma unroll 2
         for (int pp = vp0; pp < n; pp += PPAR) {
             float vf[8];
@@ -452,7 +468,8 @@ nsd_attn_step_kernel(AttnArgs a)
         }
         nsd_wave_sync();
     }
-    // the position groups' partial sums meet in the lanes of group 0
+    // the position groups' partial sums meet in the lanes of group 0 (row exchanges by permlane16/32_swap instead of
+    // these permutes were measured: 33.9 -> 37.8 us per launch, not kept)
     for (int d = LP; d < 64; d <<= 1) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
