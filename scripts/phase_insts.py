@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT))
 from silent_speech_amd import build as B
 
 OUT = ROOT / "build" / "diag"
-STOPS = (1, 2, 3, 4)
+STOPS = (1, 2, 3, 9, 12, 4)
 REPS = 3
 
 if sys.argv[1] == "build":

@@ -17,10 +17,10 @@ per = collections.defaultdict(dict)
 for r in csv.DictReader(open(f)):
     if "nsd_step_kernel" in r["Kernel_Name"]:
         per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
-ids = sorted(per)[-15:]
-names = ["phase 1 (state, records)", "passes (softmax, emit)", "bounds + scoring", "selection", "write-back"]
+ids = sorted(per)[-21:]
+names = ["phase 1 (state, records)", "passes (softmax, emit)", "bounds + scoring", "selection: set-up, threshold", "selection: ranking", "selection: holes, ties", "write-back"]
 prev = collections.defaultdict(float)
-for k in range(5):
+for k in range(7):
     d = per[ids[3 * k]]                      # first of the three launches of this build
     w = d["SQ_WAVES"]
     print(f"{names[k]:28s} " + "  ".join(f"{c[9:]} {(d[c] - prev[c]) / w:7.1f}" for c in

@@ -49,7 +49,7 @@ __device__ unsigned long long *g_nsd_stamps = nullptr;
 #elif defined(NSD_STOP_AT)
 // Diagnostic build only: the kernel ends at one phase boundary, so that instruction counters of builds that end
 // at successive boundaries, launched on the same input, give the instructions of each phase.
-#define NSD_STAMP(k) do { if ((k) == NSD_STOP_AT) return; } while (0)
+#define NSD_STAMP(k) do { if ((k) == NSD_STOP_AT || ((k) == 4 && (NSD_STOP_AT == 9 || NSD_STOP_AT == 12))) return; } while (0)
 #define NSD_STAMP_VALUE(k, v) do { } while (0)
 #else
 #define NSD_STAMP(k) do { } while (0)
@@ -826,6 +826,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
             if (w0) L.sel(r0) = compacted ? L.sIdx()[f0] : f0;
             if (w1) L.sel(r1) = compacted ? L.sIdx()[f1] : f1;
             claimed = (uint32_t)__popcll(gballot(w0)) + (uint32_t)__popcll(gballot(w1));
+            NSD_STAMP(12);
         }
         nsd_wave_sync();
         // equal keys show up as a rank claimed twice: inside the top-B that leaves a hole, at its lower
