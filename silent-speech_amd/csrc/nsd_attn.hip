@@ -303,7 +303,9 @@ nsd_swiglu_kernel(const T *gu, long long rows, int inter, T *out)
     Vec16<T>::load(gu + r * 2 * inter + inter + i, u);
 #pragma unroll
     for (int e = 0; e < VN; ++e) {
-        const float s = to_f(from_f<T>(g[e] / (1.0f + expf(-g[e]))));            // silu, stored in the element type
+        // silu, stored in the element type; hardware exp2 and reciprocal (about 1 ulp each, below what the element
+        // type keeps): the precise expf and division made this kernel arithmetic-bound
+        const float s = to_f(from_f<T>(g[e] * __frcp_rn(1.0f + __expf(-g[e]))));
         g[e] = s * u[e];
     }
     Store16<T>::store(out + r * inter + i, g);

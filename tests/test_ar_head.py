@@ -352,3 +352,23 @@ def test_rope_kv_append_kernel(dtype, heads, kvh, hd, M):
     assert float((q.float() - want[:, :heads].float()).abs().max()) <= tol
     assert float((k.float() - want[:, heads:].float()).abs().max()) <= tol
     assert torch.equal(v, qkv[:, heads + kvh:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,rows,inter", [(torch.float32, 5, 160), (torch.bfloat16, 33, 8192), (torch.bfloat16, 3, 64)])
+def test_swiglu_kernel(dtype, rows, inter):
+    """nsd_swiglu against torch: silu(gate) rounded to the element type, times up."""
+    from silent_speech_amd import lib as _lib
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(inter + rows)
+    gu = (torch.randn(rows, 2 * inter, generator=g, device=dev) * 3.0).to(dtype)
+    out = torch.empty(rows, inter, dtype=dtype, device=dev)
+    rc = L.nsd_swiglu(gu.data_ptr(), rows, inter, 0 if dtype == torch.float32 else 1, out.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    gate, up = gu[:, :inter].float(), gu[:, inter:].float()
+    want = (torch.nn.functional.silu(gate).to(dtype).float() * up).to(dtype).float()
+    tol = 3e-6 if dtype == torch.float32 else 1.6e-2
+    err = (out.float() - want).abs() / want.abs().clamp(min=1.0)
+    assert float(err.max()) <= tol
