@@ -625,11 +625,17 @@ nsd_step_kernel(StepArgs a, NsdParams P)
                 double m = kk[0];
 #pragma unroll
                 for (int c = 1; c < KMAX; ++c) m = kv[c] ? fmax(m, kk[c]) : m;
-#pragma unroll
-                for (int d = 1; d < G; d <<= 1) {
-                    const double o = __shfl_xor(m, d);
-                    m = d < cell ? fmax(m, o) : fmin(m, o);
-                }
+                // (every aligned block of d lanes agrees before the step at distance d: register moves up to 8)
+                auto red = [&](auto dist) {
+                    constexpr int D = decltype(dist)::value;
+                    if (D < G) {
+                        const double o = nsd_xchg_f64<D>(m);
+                        m = D < cell ? fmax(m, o) : fmin(m, o);
+                    }
+                };
+                red(std::integral_constant<int, 1>{});  red(std::integral_constant<int, 2>{});
+                red(std::integral_constant<int, 4>{});  red(std::integral_constant<int, 8>{});
+                red(std::integral_constant<int, 16>{}); red(std::integral_constant<int, 32>{});
                 uint32_t n = 0;
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) {
