@@ -60,7 +60,8 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--no-cpu", "--steps", "1"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0
-    assert p.stderr.count("no HIP device visible") == 2
+    # (the launcher ends the other rank as soon as one has failed: the second message may not get out)
+    assert 1 <= p.stderr.count("no HIP device visible") <= 2
     assert '"n_gpus"' not in p.stdout
 
 
