@@ -1026,14 +1026,20 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     }
     NSD_STAMP(2);
     nsd_wave_sync();
-    // more candidates than two scoring rounds take: bound them away first (up to that size the sweep costs what
-    // it saves; it is repeated only while the buffer still exceeds two rounds and the last sweep removed something)
+    // many candidates: bound them away before a table look-up is spent on them (repeated only while the buffer still
+    // exceeds the threshold and the last sweep removed something)
     {
-        bool again = act && C > 2u * (uint32_t)G;
+        // measured: with one utterance per wave the sweep pays from a quarter round beyond the first (mean launch
+        // 17.1 -> 16.9 us at beam 16, the busiest step 33 -> 19 us; from 64 candidates on it costs more than it
+        // saves, 17.7 us; at beam 32, where a step has some 160 candidates, the lower threshold only repeats the
+        // sweep: 47.9 against 46.8 us); with two or four utterances per wave it pays from two rounds (281 us against
+        // 308 from one)
+        const uint32_t NSD_SWEEP_AT = (G == 64 && B <= 16) ? 80u : 2u * (uint32_t)G;
+        bool again = act && C > NSD_SWEEP_AT;
         for (int it = 0; it < 3 && __builtin_amdgcn_ballot_w64(again) != 0; ++it) {
             const uint32_t before = C;
             bound_prune(again);
-            again = again && C > 2u * (uint32_t)G && C < before;
+            again = again && C > NSD_SWEEP_AT && C < before;
         }
     }
     // nothing scored or pruned so far and the upper half of the buffer free: transitions can be kept
