@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NSD_VERSION        101
+#define NSD_VERSION        102
 #define NSD_V              40
 #define NSD_NBASE          37
 #define NSD_SPACE          36
