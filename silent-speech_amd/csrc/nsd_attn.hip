@@ -544,8 +544,9 @@ nsd_attn_ctx_kernel(CtxArgs a)
         // The value fragments of the first DTB head-dimension tiles are requested here, before the scores are
         // reduced, so that their round trip runs under the softmax (one round trip per tile otherwise); the launch
         // has few waves (1.5 per SIMD at 64 utterances x 8 kv heads) and may use the registers of those that are
-        // not there.  Splitting the head dimension over more workgroups was measured and is slower (the repeated
-        // key reads cost more than the extra waves bring: 18.9 -> 22.8 -> 33.4 us for 1 / 2 / 4 workgroups).
+        // not there.  Splitting the head dimension over more workgroups was measured and is slower (18.9 -> 22.8 ->
+        // 33.4 us for 1 / 2 / 4 workgroups); staging keys and values once per workgroup in LDS changes nothing
+        // (19.8 us), and without its output stores the kernel still takes 15.8 us.
         constexpr int DTN = HD / 16, DTB = NP <= 4 ? DTN : 4;
         uint2 vlo[DTB][NP], vhi[DTB][NP];
         auto fetch_v = [&](int dt0) {
