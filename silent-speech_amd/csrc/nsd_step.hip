@@ -32,6 +32,7 @@
 // inference_emg_llm.py:239-297 (I) and eval_ar.py:243-313 (E) of the
 // reference; all score arithmetic is fp64 in the reference's operation order.
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include <type_traits>
 #include "nsd_device.h"
 
@@ -44,8 +45,11 @@ constexpr uint32_t SEL_NONE = 0xFFFFFFFFu;
 // Diagnostic build only (never the shipped library): lane 0 of every wave stores the shader clock at the
 // phase boundaries into a buffer of its own that no other code reads.
 __device__ unsigned long long *g_nsd_stamps = nullptr;
-#define NSD_STAMP(k) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define NSD_STAMP_VALUE(k, v) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[(size_t)wave_id * 16 + (k)] = (unsigned long long)(v); } while (0)
+#ifndef NSD_REPEAT
+#define NSD_REPEAT 1
+#endif
+#define NSD_STAMP(k) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[((size_t)wave_id * NSD_REPEAT + rep) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NSD_STAMP_VALUE(k, v) do { if (g_nsd_stamps && lane == 0) g_nsd_stamps[((size_t)wave_id * NSD_REPEAT + rep) * 16 + (k)] = (unsigned long long)(v); } while (0)
 #elif defined(NSD_STOP_AT)
 // Diagnostic build only: the kernel ends at one phase boundary, so that instruction counters of builds that end
 // at successive boundaries, launched on the same input, give the instructions of each phase.
@@ -87,10 +91,23 @@ NSD_D StepArgsK *fresh_args()
     return p;
 }
 
-NSD_D NsdTables fresh_tables(StepArgsK *k)
+NSD_D NsdTables fresh_tables_raw(StepArgsK *k)
 {
     NsdTables t;
     __builtin_memcpy(&t, &k->tab, sizeof(t));
+    return t;
+}
+
+// ORD >= 0: the launcher guarantees that the tables have this n-gram order, so everything derived from it is a
+// constant of the instantiation
+template <int ORD>
+NSD_D NsdTables fresh_tables(StepArgsK *k)
+{
+    NsdTables t = fresh_tables_raw(k);
+    if constexpr (ORD >= 0) {
+        t.order = ORD;
+        t.ctx_sym_mask = ORD >= 2 ? ((1ull << (6 * (ORD >= 2 ? ORD - 1 : 0))) - 1ull) : 0ull;
+    }
     return t;
 }
 
@@ -132,12 +149,30 @@ struct GroupLds {
 
 constexpr int BEAM_BYTES = 9 * 8 + 8 * 4;
 
-NSD_HD uint32_t max_cands_per_beam(int B, int variant)
+NSD_HD constexpr uint32_t max_cands_per_beam(int B, int variant)
 {
     const uint32_t kfb = (uint32_t)(B < NSD_V ? B : NSD_V);
     const uint32_t lex = NSD_NBASE + (variant == NSD_VARIANT_I ? 0u : 1u);   // 37 characters (+ EOS)
     const uint32_t fb = kfb + (variant == NSD_VARIANT_U ? 1u : 0u);
     return lex > fb ? lex : fb;
+}
+
+// Candidate buffer entries per utterance: room for a pruned buffer (B) plus the most one pass can add, and enough
+// that ordinary steps (about 10 candidates per hypothesis) never prune before the final selection.
+NSD_HD constexpr uint32_t step_cap(int B, int G, int variant)
+{
+    uint32_t cap = (uint32_t)B + (uint32_t)(G / 8) * max_cands_per_beam(B, variant);
+    if (cap < 10u * (uint32_t)B) cap = 10u * (uint32_t)B;
+    if (cap < 6u * (uint32_t)G) cap = 6u * (uint32_t)G;
+    return (cap + 1u) & ~1u;
+}
+
+// LDS bytes of one utterance's region
+NSD_HD constexpr uint32_t step_lds_per_utt(int B, int G, int variant)
+{
+    const uint32_t bytes = (uint32_t)((B + 1) & ~1) * (uint32_t)BEAM_BYTES +
+                           step_cap(B, G, variant) * (8u + 4u + (variant == NSD_VARIANT_E ? 8u : 0u)) + 2u * (uint32_t)G * 12u + 16u;
+    return (bytes + 15u) & ~15u;
 }
 
 // fp64 score of a character candidate: hypothesis score + (log-prob + beta * LM value of the extended text), the LM
@@ -197,24 +232,12 @@ static int nsd_step_group(int B, int N, int hint)
     return N >= 16384 ? (gmin < 32 ? 32 : gmin) : 64;
 }
 
-static size_t nsd_step_lds_per_utt(int B, int G, int variant, uint32_t *cap_out)
-{
-    // room for a pruned buffer (B) plus the most one pass can add, and enough that ordinary steps
-    // (about 10 candidates per hypothesis) never prune before the final selection
-    uint32_t cap = (uint32_t)B + (uint32_t)(G / 8) * max_cands_per_beam(B, variant);
-    if (cap < 10u * (uint32_t)B) cap = 10u * (uint32_t)B;
-    if (cap < 6u * (uint32_t)G) cap = 6u * (uint32_t)G;
-    cap = (cap + 1u) & ~1u;
-    size_t bytes = (size_t)((B + 1) & ~1) * BEAM_BYTES + (size_t)cap * (8 + 4 + (variant == NSD_VARIANT_E ? 8 : 0)) +
-                   (size_t)2 * G * 12 + 16;
-    bytes = (bytes + 15) & ~(size_t)15;
-    if (cap_out) *cap_out = cap;
-    return bytes;
-}
 
-template <int G, int VARIANT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
-nsd_step_kernel(StepArgs a, NsdParams P)
+// BT: the beam, known at compile time (0 = taken from the arguments).  ORD: the language model is on and has this
+// order (-1 = both taken from the arguments).  The launcher picks the instantiation that matches the call; the
+// run-time form serves every other shape.
+template <int G, int VARIANT, int BT, int ORD>
+NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
 {
     constexpr int UPW = 64 / G;                   // utterances per wave
     constexpr int RPP = G / 8;                    // logits rows per pass and utterance
@@ -227,7 +250,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
     const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + wid;
     const long long ull = wave_id * UPW + g;
-    const int B = a.B;
+    const int B = BT ? BT : a.B;
     bool act = ull < (long long)a.N;
     const int u = act ? (int)ull : 0;
     // The hypothesis records are requested together with the utterance word, for every slot of the beam
@@ -291,10 +314,11 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         return (uint32_t)__popcll(gb & ((1ull << gl) - 1ull));
     };
 
-    const bool use_lm = P.use_lm != 0 && a.tab.order > 0;
-    const int order = a.tab.order;
-    const uint32_t CAP = a.cap;
-    GroupLds L = carve<G>(smem + (size_t)KN * 16 + ((size_t)wid * UPW + g) * a.lds_per_utt, B, CAP, VARIANT == NSD_VARIANT_E);
+    const bool use_lm = ORD >= 0 ? ORD > 0 : (P.use_lm != 0 && a.tab.order > 0);
+    const int order = ORD >= 0 ? ORD : a.tab.order;
+    const uint32_t CAP = BT ? step_cap(BT, G, VARIANT) : a.cap;
+    const uint32_t lds_per_utt = BT ? step_lds_per_utt(BT, G, VARIANT) : a.lds_per_utt;
+    GroupLds L = carve<G>(smem + (size_t)KN * 16 + ((size_t)wid * UPW + g) * lds_per_utt, B, CAP, VARIANT == NSD_VARIANT_E);
 
     // ---------------- phase 1: hypothesis state -> LDS ----------------
     bool my_live = false;
@@ -389,7 +413,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // 2 C <= CAP) the n-gram transition of a character or space candidate is left in the unused top of
     // the buffer (entry CAP-1-i for candidate i), where the write phase finds it for the survivors.
     auto score_new = [&](uint32_t from, bool keep) {
-        const NsdTables T = fresh_tables(fresh_args());
+        const NsdTables T = fresh_tables<ORD>(fresh_args());
         const uint32_t rounds = wave_max(act && C > from ? (C - from + G - 1) / G : 0u);
         for (uint32_t rd = 0; rd < rounds; ++rd) {
             const uint32_t i = from + rd * G + gl;
@@ -1066,7 +1090,7 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // ---------------- write the surviving hypotheses ----------------
     bool fin = true;
     StepArgsK *W = fresh_args();                   // output pointers are fetched here, not held from the top
-    const NsdTables WT = fresh_tables(W);
+    const NsdTables WT = fresh_tables<ORD>(W);
     if (act && gl < nsel) {
         uint32_t mysel = L.sel(gl);
         if (mysel >= C) mysel = 0;                 // only reachable with NaN keys
@@ -1149,6 +1173,23 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     NSD_STAMP(5);
 }
 
+template <int G, int VARIANT, int BT, int ORD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+nsd_step_kernel(StepArgs a, NsdParams P)
+{
+#ifdef NSD_REPEAT
+    // Diagnostic build only: the whole step runs NSD_REPEAT times on the same input (the caller passes distinct
+    // in / out states), so that stamps of the later runs show a wave's time with caches and translations warm.
+    for (int rep = 0; rep < NSD_REPEAT; ++rep) {
+        nsd_step_body<G, VARIANT, BT, ORD>(a, P, rep);
+        __builtin_amdgcn_s_waitcnt(0);
+        nsd_wave_sync();
+    }
+#else
+    nsd_step_body<G, VARIANT, BT, ORD>(a, P, 0);
+#endif
+}
+
 #ifdef NSD_STAMPS
 extern "C" int nsd_debug_set_stamps(unsigned long long *p)
 {
@@ -1156,7 +1197,7 @@ extern "C" int nsd_debug_set_stamps(unsigned long long *p)
 }
 #endif
 
-template <int G, int VARIANT>
+template <int G, int VARIANT, int BT, int ORD>
 static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     constexpr int UPW = 64 / G;
@@ -1174,17 +1215,38 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
     const long long n_waves = ((long long)N + UPW - 1) / UPW;
     const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
     if (ev0 || ev1)      // the events take the kernel's own start / end timestamps (no marker packets in between)
-        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves),
+        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD>), dim3(grid), dim3(64 * waves),
                               lds_fixed + lds_per_wave * (uint32_t)waves, s, ev0, ev1, 0, a, p);
     else
-        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT>), dim3(grid), dim3(64 * waves), lds_fixed + lds_per_wave * (uint32_t)waves, s, a, p);
+        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD>), dim3(grid), dim3(64 * waves),
+                           lds_fixed + lds_per_wave * (uint32_t)waves, s, a, p);
+}
+
+// The instantiation for this call: beams 8, 16 and 32 with a 5-gram model (the shapes of the benchmark
+// configurations) have kernels of their own at 32 and 64 lanes per utterance; everything else runs the form that
+// reads beam and order from its arguments.  NSD_STEP_GENERIC=1 in the environment forces the latter (a debugging
+// aid: the two must give the same bits).
+template <int G, int VARIANT>
+static void launch_shape(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    static const bool generic_only = [] { const char *e = getenv("NSD_STEP_GENERIC"); return e && e[0] == '1'; }();
+    const bool lm5 = p.use_lm != 0 && a.tab.order == 5;
+    if constexpr (G >= 32) {
+        if (lm5 && !generic_only) {
+            if (a.B == 16) return launch_gv<G, VARIANT, 16, 5>(a, p, N, s, ev0, ev1);
+            if (a.B == 8)  return launch_gv<G, VARIANT, 8, 5>(a, p, N, s, ev0, ev1);
+            if (a.B == 32) return launch_gv<G, VARIANT, 32, 5>(a, p, N, s, ev0, ev1);
+        }
+    }
+    launch_gv<G, VARIANT, 0, -1>(a, p, N, s, ev0, ev1);
 }
 
 template <int VARIANT>
 static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int G = nsd_step_group(a.B, N, p.lanes_per_utt);
-    a.lds_per_utt = (uint32_t)nsd_step_lds_per_utt(a.B, G, p.variant, &a.cap);
+    a.cap = step_cap(a.B, G, p.variant);
+    a.lds_per_utt = step_lds_per_utt(a.B, G, p.variant);
     {   // staged trie records: what was asked for, within the trie, the documented maximum and a workgroup's LDS
         uint32_t kn = p.lds_trie_nodes > 0 ? (uint32_t)p.lds_trie_nodes : 0u;
         if (kn > a.tab.n_nodes) kn = a.tab.n_nodes;
@@ -1193,9 +1255,9 @@ static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s
         a.lds_nodes = kn;
     }
     switch (G) {
-    case 16: launch_gv<16, VARIANT>(a, p, N, s, ev0, ev1); break;
-    case 32: launch_gv<32, VARIANT>(a, p, N, s, ev0, ev1); break;
-    default: launch_gv<64, VARIANT>(a, p, N, s, ev0, ev1); break;
+    case 16: launch_shape<16, VARIANT>(a, p, N, s, ev0, ev1); break;
+    case 32: launch_shape<32, VARIANT>(a, p, N, s, ev0, ev1); break;
+    default: launch_shape<64, VARIANT>(a, p, N, s, ev0, ev1); break;
     }
 }
 
