@@ -65,6 +65,8 @@ extern "C" {
 #define NSD_U_NBEAMS_MASK   0xFFu
 #define NSD_U_DONE          0x100u  /* every hypothesis finished (ns_utils.py:274-275) */
 #define NSD_U_ERR_TOPK      0x200u  /* fall-back asked for k > V in variant I/E (torch.topk raises) */
+#define NSD_U_ERR_INTERNAL  0x400u  /* a step's candidate buffer would have overflowed: a defect of the library, never
+                                       expected; the utterance's result is not to be trusted */
 #define NSD_U_STEPS_SHIFT   16
 
 /* ---- replicated symbolic tables ------------------------------------ */

@@ -1,6 +1,9 @@
 """Randomised parity sweep: the HIP decoder against the C checker (parents, tokens, lexicon masks per step,
 fp64 scores, ids) over random decoder variants, beams, n-gram orders, weights, lexicon sizes, logit margins
-and lanes-per-utterance.  usage: fuzz_parity.py [n_cases] [seed] [only_case]"""
+and lanes-per-utterance.  usage: fuzz_parity.py [n_cases] [seed] [only_case] [hot]
+With `hot` the cases are drawn around the shapes that have nsd_step instantiations of their own (beams 8 / 16 / 32
+with a 5-gram model, 32 or 64 lanes per utterance), with negative LM weights and with lexicons large enough that the
+bound sweep runs."""
 import random, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -36,13 +39,37 @@ def random_cases(n_cases, seed):
         yield k, case
 
 
+def hot_cases(n_cases, seed):
+    rng = random.Random(seed)
+    for k in range(n_cases):
+        variant = rng.choice("UIIE")
+        beam = rng.choice([8, 16, 16, 32])
+        case = dict(variant=variant, beam=beam, lm_order=rng.choice([5, 5, 5, 3]), beta=rng.choice([-0.3, -0.05, 0.0, 0.05, 0.3, 1.0]),
+                    margin=rng.choice([0.0, 2.0, 6.0, 20.0, 60.0]), gamma=rng.choice([0.0, 1.0, 3.5]),
+                    kappa=rng.choice([0.0, 0.35]), alpha=rng.choice([0.0, 0.6, 1.0]), min_len_for_eos=rng.choice([0, 3, 8]),
+                    max_new_tokens=rng.choice([7, 24, 40, 64]), n_words=rng.choice([3, 40, 200, 3000, 20000]), lex_seed=rng.randrange(100),
+                    max_len=rng.choice([3, 8, 12]), n_corpus=rng.choice([0, 50, 2000]), corpus_seed=rng.randrange(100),
+                    n_utts=rng.choice([1, 7, 64, 200]), target_seed=rng.randrange(100), base_seed=rng.randrange(1 << 30),
+                    min_words=1, max_words=rng.choice([1, 4]), lanes=rng.choice([0, 32, 64]), name=f"hot{k}",
+                    allow_eos_anytime=rng.random() < 0.8)
+        if rng.random() < 0.4:
+            case["alphabet"] = synth.BASE_CHARS[:36]
+        if rng.random() < 0.3:
+            case["extra_words"] = rng.sample(["don't", "it's", "zq'x", "new york", "a b", "ice cream cone", "x-ray"], 3)
+        if case["n_words"] == 20000:                    # (three letters do not make that many distinct words)
+            case["n_utts"] = min(case["n_utts"], 64)
+            case["max_len"] = max(case["max_len"], 8)
+        yield k, case
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+    hot = len(sys.argv) > 4 and sys.argv[4] == "hot"
     dev = torch.device("cuda", 0)
     t0 = time.time()
-    for k, case in random_cases(n_cases, seed):
+    for k, case in (hot_cases if hot else random_cases)(n_cases, seed):
         if only >= 0 and k != only:
             continue
         ws, ids, lens, scores, ref, err = _run_case_batched(case, dev)

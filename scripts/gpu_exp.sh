@@ -13,10 +13,13 @@ if [ "$nf" -gt 0 ]; then
   [ $rc -ne 0 ] && exit $rc
 fi
 bash scripts/bench_libs.sh "$@" || exit 1
-for so in "$@"; do
-  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --no-cpu --utts 131072 --steps 5 --warmup 1 --also= > $out/big_$(basename $so).json 2> $out/big_$(basename $so).err || exit 1
-  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --open-lexicon --beam 32 --no-cpu --steps 6 --also= > $out/open_$(basename $so).json 2> $out/open_$(basename $so).err || exit 1
-  python - $so $out/big_$(basename $so).json $out/open_$(basename $so).json <<'PY'
+for arg in "$@"; do
+  so=${arg%%:*}; mode=${arg#*:}; [ "$mode" = "$arg" ] && mode=9
+  t=$(basename $so)_m$mode
+  export NSD_STEP_MODE=$mode
+  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --no-cpu --utts 131072 --steps 5 --warmup 1 --also= > $out/big_$t.json 2> $out/big_$t.err || exit 1
+  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --open-lexicon --beam 32 --no-cpu --steps 6 --also= > $out/open_$t.json 2> $out/open_$t.err || exit 1
+  python - $arg $out/big_$t.json $out/open_$t.json <<'PY'
 import json, sys
 b = json.load(open(sys.argv[2]))["roofline"]; o = json.load(open(sys.argv[3]))["roofline"]
 print(sys.argv[1], "big launch %.1f us frac %.3f | open32 launch %.2f us frac %.3f" % (b["avg_launch_us"], b["frac"], o["avg_launch_us"], o["frac"]))

@@ -210,6 +210,51 @@ NSD_D void nsd_row_log_softmax5(float (&x)[5])
     x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c - lse;
 }
 
+// The same log-softmax with the row spread over 4 consecutive lanes, 10 consecutive elements per lane.  Same
+// summation tree, hence the same bits: a lane sums its two groups of five left to right and adds the two sums
+// (the distance-1 step of the 8-lane form), then lane distances 1 and 2 here are distances 2 and 4 there.
+NSD_D void nsd_row_log_softmax10(float (&x)[10])
+{
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max_f32 %0, %0, %10\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(m) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+          "v"(x[8]), "v"(x[9]));
+    nsd_f2 d[5], e[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        d[k] = nsd_f2{x[2 * k], x[2 * k + 1]} - m;
+        e[k] = nsd_det_expf2(d[k]);
+    }
+    float sa = e[0].x;                            // elements 0..4, left to right
+    sa = sa + e[0].y;
+    sa = sa + e[1].x;
+    sa = sa + e[1].y;
+    sa = sa + e[2].x;
+    float sb = e[2].y;                            // elements 5..9
+    sb = sb + e[3].x;
+    sb = sb + e[3].y;
+    sb = sb + e[4].x;
+    sb = sb + e[4].y;
+    float s = sa + sb;
+    s = s + nsd_dpp_xor1(s);
+    s = s + nsd_dpp_xor2(s);
+    const float lse = nsd_det_logf(s);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        d[k] = d[k] - lse;
+        x[2 * k] = d[k].x;
+        x[2 * k + 1] = d[k].y;
+    }
+}
+
 // ---------------------------------------------------------------------
 // n-gram tables
 // ---------------------------------------------------------------------

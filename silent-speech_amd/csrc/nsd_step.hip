@@ -87,7 +87,9 @@ using StepArgsK = const __attribute__((address_space(4))) StepArgs;
 NSD_D StepArgsK *fresh_args()
 {
     StepArgsK *p = (StepArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+#ifndef NSD_NO_FRESH
     asm volatile("" : "+s"(p));
+#endif
     return p;
 }
 
@@ -236,11 +238,16 @@ static int nsd_step_group(int B, int N, int hint)
 // BT: the beam, known at compile time (0 = taken from the arguments).  ORD: the language model is on and has this
 // order (-1 = both taken from the arguments).  The launcher picks the instantiation that matches the call; the
 // run-time form serves every other shape.
-template <int G, int VARIANT, int BT, int ORD>
+// QUAD: a logits row is spread over 4 lanes (10 elements each) instead of 8, rows belong to hypotheses by position
+// (row slot h of a pass = hypothesis pass * RPP + h, no compaction of the live ones), and the first pass's rows are
+// requested together with the hypothesis state: for copies of the decoder whose hypotheses are (nearly) all live.
+template <int G, int VARIANT, int BT, int ORD, bool QUAD>
 NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
 {
     constexpr int UPW = 64 / G;                   // utterances per wave
-    constexpr int RPP = G / 8;                    // logits rows per pass and utterance
+    constexpr int RL = QUAD ? 4 : 8;              // lanes per logits row
+    constexpr int EPL = NSD_V / RL;               // logits per lane
+    constexpr int RPP = G / RL;                   // logits rows per pass and utterance
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -269,6 +276,19 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         ld_ctx = a.in.ctx[si];     ld_hist = a.in.hist[si];
     }
     const int nbeams = (int)(um & NSD_U_NBEAMS_MASK);
+    // logits of the next pass are requested before the current pass is processed; with rows assigned by position
+    // the first pass's are requested here, next to the state (rows of all B slots exist, whatever the beam count)
+    const int j = lane & (RL - 1);
+    const int rslot = gl / RL;                    // row slot of this lane inside a pass
+    float xn[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) xn[k] = 0.0f;
+    if (QUAD && act && rslot < B) {
+        const float2 *row = reinterpret_cast<const float2 *>(
+            a.logits + (((uint32_t)u * (uint32_t)B + (uint32_t)rslot) * (uint32_t)NSD_V + (uint32_t)(j * EPL)));
+#pragma unroll
+        for (int k = 0; k < EPL / 2; ++k) { const float2 v = row[k]; xn[2 * k] = v.x; xn[2 * k + 1] = v.y; }
+    }
 
     // optional: the upper trie levels (the first node records in breadth-first order) copied to LDS by the whole
     // workgroup, before any wave leaves
@@ -337,32 +357,38 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         const uint32_t flags = meta & 0xffu;
         const int glen = (int)(meta >> 8);
         my_live = !(flags & NSD_F_FINISHED);
-        // second hop: trie node and n-gram context records
+        // second hop: trie node and n-gram context records.  The three reads (node record, context record, terminal
+        // log-prob of the stripped context under a pending space) are requested together, outside any divergent
+        // branch: a lane without such a record reads its own logits row instead (160 readable bytes, discarded).
         uint64_t sym = 0;
         uint32_t lmbase = 0;
         double bo = 0.0, term_s = 0.0;
         const bool in_lex = my_live && !(flags & NSD_F_DEAD) && node != NSD_NODE_DEAD;
-        ulonglong2 nrec = {0ull, 0ull};
-        if (in_lex) {
-            if (node < KN) nrec = reinterpret_cast<const ulonglong2 *>(smem)[node];
-            else nrec = *reinterpret_cast<const ulonglong2 *>(&a.tab.nodes[node]);
+        const int pend = (flags & NSD_F_PENDING_SPACE) ? 1 : 0;
+        const int ms = 1 + glen - pend;                            // symbols in '^' + stripped surface
+        const bool lm_here = use_lm && in_lex;
+        const bool has_ce = lm_here && ctxe_id != NSD_CTX_NONE;
+        const bool tail_s = lm_here && ms + 1 >= order;            // terminal window of the stripped surface exists
+        const bool want_t = tail_s && pend && ctx_id != NSD_CTX_NONE;
+        const char *own_row = reinterpret_cast<const char *>(a.logits + (size_t)i * NSD_V);
+        const char *pn = in_lex ? reinterpret_cast<const char *>(a.tab.nodes + node) : own_row;
+        const char *pc = has_ce ? reinterpret_cast<const char *>(a.tab.ctx_recs + ctxe_id) : own_row;
+        const char *pt = want_t ? reinterpret_cast<const char *>(&a.tab.ctx_recs[ctx_id].term) : own_row;
+        ulonglong2 nrec = *reinterpret_cast<const ulonglong2 *>(pn);
+        const ulonglong2 q0 = reinterpret_cast<const ulonglong2 *>(pc)[0];   // backoff, term
+        const ulonglong2 q1 = reinterpret_cast<const ulonglong2 *>(pc)[1];   // symmask, child_base
+        const double tterm = *reinterpret_cast<const double *>(pt);
+        if (KN && in_lex && node < KN) nrec = reinterpret_cast<const ulonglong2 *>(smem)[node];
+        if (!in_lex) nrec = ulonglong2{0ull, 0ull};
+        if (has_ce) {
+            bo = __longlong_as_double((long long)q0.x);
+            sym = q1.x;
+            lmbase = (uint32_t)q1.y;
+            if (!pend) term_s = __longlong_as_double((long long)q0.y);
         }
-        if (use_lm && in_lex) {
-            const int pend = (flags & NSD_F_PENDING_SPACE) ? 1 : 0;
-            const int ms = 1 + glen - pend;                        // symbols in '^' + stripped surface
-            if (ctxe_id != NSD_CTX_NONE) {
-                const NsdCtxRec *r = a.tab.ctx_recs + ctxe_id;
-                const ulonglong2 q0 = reinterpret_cast<const ulonglong2 *>(r)[0];   // backoff, term
-                const ulonglong2 q1 = reinterpret_cast<const ulonglong2 *>(r)[1];   // symmask, child_base
-                bo = __longlong_as_double((long long)q0.x);
-                sym = q1.x;
-                lmbase = (uint32_t)q1.y;
-                if (!pend) term_s = __longlong_as_double((long long)q0.y);
-            }
-            if (ms + 1 >= order) {                                 // terminal window of the stripped surface exists
-                if (pend) term_s = ctx_id != NSD_CTX_NONE ? a.tab.ctx_recs[ctx_id].term : a.tab.unseen;
-                else if (ctxe_id == NSD_CTX_NONE) term_s = a.tab.unseen;
-            }
+        if (tail_s) {
+            if (pend) term_s = ctx_id != NSD_CTX_NONE ? tterm : a.tab.unseen;
+            else if (ctxe_id == NSD_CTX_NONE) term_s = a.tab.unseen;
         }
         uint64_t mask = nrec.x;
         const uint32_t child = (uint32_t)nrec.y;
@@ -380,7 +406,7 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
     }
     const uint64_t live_gb = gballot(my_live);
     const int nlive = __popcll(live_gb);
-    if (my_live) L.live(gprefix(live_gb)) = (uint32_t)gl;
+    if (!QUAD && my_live) L.live(gprefix(live_gb)) = (uint32_t)gl;
     nsd_wave_sync();
     NSD_STAMP(1);
 
@@ -399,14 +425,22 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
     bool err_topk = false;
     uint32_t scored = 0;                          // candidates [0, scored) already have their key (group-uniform)
 
+    // (The overflow handling of the passes keeps every append inside the buffer; the s < CAP tests only make sure
+    // that a slip in it shows as NSD_U_ERR_INTERNAL instead of as writes into a neighbour's LDS.)
+    bool err_cap = false;
     auto emit = [&](bool pred, float lp, uint32_t info) {
         const uint64_t gb = gballot(pred);
         if (pred) {
             const uint32_t s = C + gprefix(gb);
-            L.cInfo()[s] = info;
-            reinterpret_cast<float *>(L.cKey())[2 * s] = lp;
+            if (s < CAP) {
+                L.cInfo()[s] = info;
+                reinterpret_cast<float *>(L.cKey())[2 * s] = lp;
+            } else {
+                err_cap = true;
+            }
         }
         C += (uint32_t)__popcll(gb);
+        if (C > CAP) C = CAP;
     };
 
     // score candidates [from, C) of this group, one lane each.  With `keep` (group-uniform; needs
@@ -914,28 +948,43 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
     const bool may_overflow = __builtin_amdgcn_ballot_w64(act && L.total()[0] > CAP) != 0;
 
     // ---------------- passes: log-softmax, candidates, scores ----------------
-    const int j = lane & 7;
-    const int npass = act ? (nlive + RPP - 1) / RPP : 0;
+    const int npass = act ? ((QUAD ? nbeams : nlive) + RPP - 1) / RPP : 0;
     const int npass_max = (int)wave_max((uint32_t)npass);
-    // logits of the next pass are requested before the current pass is processed
-    float xn[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     auto fetch_row = [&](int pass) {
-        const int slot = pass * RPP + (gl >> 3);
-        if (act && slot < nlive) {
-            const float *row = fresh_args()->logits + (((uint32_t)u * (uint32_t)B + L.live(slot)) * (uint32_t)NSD_V + (uint32_t)(j * 5));
+        const int slot = pass * RPP + rslot;
+        if (act && slot < (QUAD ? nbeams : nlive)) {
+            const uint32_t hyp = QUAD ? (uint32_t)slot : L.live(slot);
+            const float *row = fresh_args()->logits + (((uint32_t)u * (uint32_t)B + hyp) * (uint32_t)NSD_V + (uint32_t)(j * EPL));
+            if (QUAD) {                            // 40-byte pieces: 8-byte aligned
 #pragma unroll
-            for (int k = 0; k < 5; ++k) xn[k] = row[k];
+                for (int k = 0; k < EPL / 2; ++k) {
+                    const float2 v = reinterpret_cast<const float2 *>(row)[k];
+                    xn[2 * k] = v.x; xn[2 * k + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) xn[k] = row[k];
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) xn[k] = 0.0f;
+            for (int k = 0; k < EPL; ++k) xn[k] = 0.0f;
         }
     };
-    if (npass_max > 0) fetch_row(0);
+    if (!QUAD && npass_max > 0) fetch_row(0);
     for (int pass = 0; pass < npass_max; ++pass) {
-        const int slot = pass * RPP + (gl >> 3);
-        const bool live = act && slot < nlive;
-        const int r = live ? (int)L.live(slot) : 0;
-        const uint32_t meta = L.bMeta(r);
+        const int slot = pass * RPP + rslot;
+        bool live;
+        int r;
+        uint32_t meta;
+        if (QUAD) {
+            r = (act && slot < nbeams) ? slot : 0;
+            meta = L.bMeta(r);
+            live = act && slot < nbeams && !(meta & NSD_F_FINISHED);
+        } else {
+            live = act && slot < nlive;
+            r = live ? (int)L.live(slot) : 0;
+            meta = L.bMeta(r);
+        }
         const uint64_t mask = live ? L.bMask(r) : 0;
         const int glen = (int)(meta >> 8);
         const bool whole = (mask >> 37) & 1;
@@ -947,105 +996,122 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         int kfb = B;
         if (kfb > NSD_V) { kfb = NSD_V; if (VARIANT != NSD_VARIANT_U && fb) err_topk = true; }
 
-        // the buffer must hold what this pass can add; otherwise prune it to its top-B first
-        if (may_overflow) {
-            uint32_t add = 0;
-            if (live && j == 0)
-                add = fb ? (uint32_t)kfb + (eos_u ? 1u : 0u)
-                         : (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + ((eos_u || eos_e) ? 1u : 0u);
+        float x[EPL];
 #pragma unroll
-            for (int off = 8; off < G; off <<= 1) add += __shfl_xor(add, off);
-            add = __shfl(add, gshift);
-            bool over = act && C + add > CAP;
-            if (__builtin_amdgcn_ballot_w64(over && C > (uint32_t)G) != 0) {
-                nsd_wave_sync();
-                bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
-                over = act && C + add > CAP;
-            }
-            if (__builtin_amdgcn_ballot_w64(over) != 0) {
-                NSD_TIC();
-                // score_new covers every group of the wave; when it does not run, the groups that are not
-                // over keep their unscored tail
-                if (__builtin_amdgcn_ballot_w64(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
-                NSD_TOC(dbg_t_score);
-                NSD_TIC();
-                prune(over);
-                NSD_TOC(dbg_t_prune);
-                if (over) scored = C;
-            }
-        }
-
-        float x[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) x[k] = xn[k];
+        for (int k = 0; k < EPL; ++k) x[k] = xn[k];
         if (pass + 1 < npass_max) fetch_row(pass + 1);
         if (pass == 0) NSD_STAMP(6);
-        nsd_row_log_softmax5(x);
+        if constexpr (QUAD) nsd_row_log_softmax10(x);
+        else nsd_row_log_softmax5(x);
 
-        // lexicon-allowed characters: the predicate is one compare of the row's mask (0 when the row is
-        // not live) with the token's bit, so the ballot is that compare's result itself
-        // One prefix sum over the lanes' candidate counts places all five (a ballot per token costs more,
-        // most of all with several utterances per wave).  The order of candidates in the buffer carries no
-        // meaning: ties are broken by the order field of the info word.
-        {
-            const uint32_t own5 = (uint32_t)((mask & ((1ull << NSD_NBASE) - 1ull)) >> (j * 5)) & 31u;   // this lane's five tokens
-            const uint32_t n = (uint32_t)__popc(own5);
-            uint32_t incl = n;
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);         // row_shr:1
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);         // row_shr:2
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);         // row_shr:4
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);         // row_shr:8
-            if (G >= 32) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1, 3
-            if (G == 64) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2, 3
-            uint32_t total;
-            if (G == 64) {
-                total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            } else if (G == 32) {
-                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                total = g ? t1 : t0;
-            } else {
-                total = (uint32_t)__shfl((int)incl, gshift + G - 1);
-            }
-            uint32_t s = C + incl - n;
-            const uint32_t v0 = (uint32_t)(j * 5);
-            const uint32_t info0 = pack_info(v0, K_CHAR, (VARIANT == NSD_VARIANT_U) ? v0 + 1u : v0, (uint32_t)r);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const bool pred = (own5 & (1u << k)) != 0;
-                if (pred) {
-                    L.cInfo()[s] = info0 + (uint32_t)k * 0x101u;     // token and order both advance by one
-                    reinterpret_cast<float *>(L.cKey())[2 * s] = x[k];
-                }
-                s += pred ? 1u : 0u;
-            }
-            C += total;
-        }
-        // EOS option (variants U and E): token 38 is element 3 of the row's last lane
-        if (VARIANT != NSD_VARIANT_I)
-            emit((eos_u || eos_e) && j == 7, x[3],
-                 pack_info(NSD_EOS, K_EOS, (VARIANT == NSD_VARIANT_U) ? 0u : 40u, (uint32_t)r));
-
-        // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
-        if (__builtin_amdgcn_ballot_w64(fb) != 0) {
-            float *rb = L.rowbuf() + (gl >> 3) * NSD_V;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) rb[j * 5 + k] = x[k];
-            nsd_wave_sync();
-            uint32_t rank[5] = {0, 0, 0, 0, 0};
+        // With 4 lanes per row a pass covers twice the rows the buffer is sized for, and the fall-back's row
+        // buffer holds half of them: when the pass might overflow the buffer or has a fall-back row (both rare),
+        // its rows emit their candidates in two halves.
+        const bool split = QUAD && (may_overflow || __builtin_amdgcn_ballot_w64(fb) != 0);
+        const int nhalf = split ? 2 : 1;
 #pragma unroll 1
-            for (int i = 0; i < NSD_V; ++i) {
-                const float o = rb[i];
+        for (int eh = 0; eh < nhalf; ++eh) {
+            const bool part = !split || (rslot / (RPP / 2)) == eh;
+            const uint64_t pmask = part ? mask : 0;
+
+            // the buffer must hold what these rows can add; otherwise prune it to its top-B first
+            if (may_overflow) {
+                uint32_t add = 0;
+                if (live && part && j == 0)
+                    add = fb ? (uint32_t)kfb + (eos_u ? 1u : 0u)
+                             : (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + ((eos_u || eos_e) ? 1u : 0u);
 #pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    rank[k] += (o > x[k] || (o == x[k] && i < j * 5 + k)) ? 1u : 0u;
+                for (int off = RL; off < G; off <<= 1) add += __shfl_xor(add, off);
+                add = __shfl(add, gshift);
+                bool over = act && C + add > CAP;
+                if (__builtin_amdgcn_ballot_w64(over && C > (uint32_t)G) != 0) {
+                    nsd_wave_sync();
+                    bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
+                    over = act && C + add > CAP;
+                }
+                if (__builtin_amdgcn_ballot_w64(over) != 0) {
+                    NSD_TIC();
+                    // score_new covers every group of the wave; when it does not run, the groups that are not
+                    // over keep their unscored tail
+                    if (__builtin_amdgcn_ballot_w64(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
+                    NSD_TOC(dbg_t_score);
+                    NSD_TIC();
+                    prune(over);
+                    NSD_TOC(dbg_t_prune);
+                    if (over) scored = C;
+                }
             }
+
+            // lexicon-allowed characters: one prefix sum over the lanes' candidate counts places all of a lane's
+            // tokens (a ballot per token costs more, most of all with several utterances per wave).  The order of
+            // candidates in the buffer carries no meaning: ties are broken by the order field of the info word.
+            {
+                const uint32_t own = (uint32_t)((pmask & ((1ull << NSD_NBASE) - 1ull)) >> (j * EPL)) & ((1u << EPL) - 1u);   // this lane's tokens
+                const uint32_t n = (uint32_t)__popc(own);
+                uint32_t incl = n;
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);         // row_shr:1
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);         // row_shr:2
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);         // row_shr:4
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);         // row_shr:8
+                if (G >= 32) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1, 3
+                if (G == 64) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2, 3
+                uint32_t total;
+                if (G == 64) {
+                    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                } else if (G == 32) {
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    total = g ? t1 : t0;
+                } else {
+                    total = (uint32_t)__shfl((int)incl, gshift + G - 1);
+                }
+                uint32_t s = C + incl - n;
+                const bool room = C + incl <= CAP;               // all of this lane's tokens fit
+                if (!room && n) err_cap = true;
+                const uint32_t v0 = (uint32_t)(j * EPL);
+                const uint32_t info0 = pack_info(v0, K_CHAR, (VARIANT == NSD_VARIANT_U) ? v0 + 1u : v0, (uint32_t)r);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const uint32_t v = (uint32_t)(j * 5 + k);
-                const uint32_t w = rank[k] + (VARIANT == NSD_VARIANT_U ? 1u : 0u);
-                emit(fb && rank[k] < (uint32_t)kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)r));
+                for (int k = 0; k < EPL; ++k) {
+                    const bool pred = room && (own & (1u << k)) != 0;
+                    if (pred) {
+                        L.cInfo()[s] = info0 + (uint32_t)k * 0x101u;     // token and order both advance by one
+                        reinterpret_cast<float *>(L.cKey())[2 * s] = x[k];
+                    }
+                    s += pred ? 1u : 0u;
+                }
+                C += total;
+                if (C > CAP) C = CAP;
             }
-            nsd_wave_sync();                       // rowbuf is reused by the next pass
+            // EOS option (variants U and E): token 38 is element 3 of the eighth lane of a row, element 8 of the fourth
+            if (VARIANT != NSD_VARIANT_I)
+                emit((eos_u || eos_e) && part && j == RL - 1, x[NSD_EOS - (RL - 1) * EPL],
+                     pack_info(NSD_EOS, K_EOS, (VARIANT == NSD_VARIANT_U) ? 0u : 40u, (uint32_t)r));
+
+            // fall-back: no lexicon-consistent option -> neural top-k over all 40 ids
+            if (__builtin_amdgcn_ballot_w64(fb && part) != 0) {
+                float *rb = L.rowbuf() + (QUAD ? rslot % (RPP / 2) : rslot) * NSD_V;
+                if (part) {
+#pragma unroll
+                    for (int k = 0; k < EPL; ++k) rb[j * EPL + k] = x[k];
+                }
+                nsd_wave_sync();
+                uint32_t rank[EPL];
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) rank[k] = 0;
+#pragma unroll 1
+                for (int i = 0; i < NSD_V; ++i) {
+                    const float o = rb[i];
+#pragma unroll
+                    for (int k = 0; k < EPL; ++k)
+                        rank[k] += (o > x[k] || (o == x[k] && i < j * EPL + k)) ? 1u : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) {
+                    const uint32_t v = (uint32_t)(j * EPL + k);
+                    const uint32_t w = rank[k] + (VARIANT == NSD_VARIANT_U ? 1u : 0u);
+                    emit(fb && part && rank[k] < (uint32_t)kfb, x[k], pack_info(v, K_FALLBACK, w, (uint32_t)r));
+                }
+                nsd_wave_sync();                   // rowbuf is reused by the next half / pass
+            }
         }
     }
     NSD_STAMP(2);
@@ -1163,17 +1229,20 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
     }
     const bool all_fin = gballot(!fin) == 0;
     const bool any_err = gballot(err_topk) != 0;
+    const bool any_cap = gballot(err_cap) != 0;
     if (act && gl == 0) {
-        uint32_t nu = (uint32_t)nsel | (((um >> NSD_U_STEPS_SHIFT) + 1u) << NSD_U_STEPS_SHIFT) | (um & NSD_U_ERR_TOPK);
+        uint32_t nu = (uint32_t)nsel | (((um >> NSD_U_STEPS_SHIFT) + 1u) << NSD_U_STEPS_SHIFT) |
+                      (um & (NSD_U_ERR_TOPK | NSD_U_ERR_INTERNAL));
         if (all_fin) nu |= NSD_U_DONE;
         if (any_err) nu |= NSD_U_ERR_TOPK;
+        if (any_cap) nu |= NSD_U_ERR_INTERNAL;
         W->out.utt[u] = nu;
         if (all_fin && W->out.done_count) atomicAdd(W->out.done_count, 1u);
     }
     NSD_STAMP(5);
 }
 
-template <int G, int VARIANT, int BT, int ORD>
+template <int G, int VARIANT, int BT, int ORD, bool QUAD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 nsd_step_kernel(StepArgs a, NsdParams P)
 {
@@ -1181,12 +1250,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // Diagnostic build only: the whole step runs NSD_REPEAT times on the same input (the caller passes distinct
     // in / out states), so that stamps of the later runs show a wave's time with caches and translations warm.
     for (int rep = 0; rep < NSD_REPEAT; ++rep) {
-        nsd_step_body<G, VARIANT, BT, ORD>(a, P, rep);
+        nsd_step_body<G, VARIANT, BT, ORD, QUAD>(a, P, rep);
         __builtin_amdgcn_s_waitcnt(0);
         nsd_wave_sync();
     }
 #else
-    nsd_step_body<G, VARIANT, BT, ORD>(a, P, 0);
+    nsd_step_body<G, VARIANT, BT, ORD, QUAD>(a, P, 0);
 #endif
 }
 
@@ -1197,7 +1266,7 @@ extern "C" int nsd_debug_set_stamps(unsigned long long *p)
 }
 #endif
 
-template <int G, int VARIANT, int BT, int ORD>
+template <int G, int VARIANT, int BT, int ORD, bool QUAD>
 static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     constexpr int UPW = 64 / G;
@@ -1215,30 +1284,41 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
     const long long n_waves = ((long long)N + UPW - 1) / UPW;
     const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
     if (ev0 || ev1)      // the events take the kernel's own start / end timestamps (no marker packets in between)
-        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD>), dim3(grid), dim3(64 * waves),
+        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD, QUAD>), dim3(grid), dim3(64 * waves),
                               lds_fixed + lds_per_wave * (uint32_t)waves, s, ev0, ev1, 0, a, p);
     else
-        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD>), dim3(grid), dim3(64 * waves),
+        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD, QUAD>), dim3(grid), dim3(64 * waves),
                            lds_fixed + lds_per_wave * (uint32_t)waves, s, a, p);
 }
 
 // The instantiation for this call: beams 8, 16 and 32 with a 5-gram model (the shapes of the benchmark
 // configurations) have kernels of their own at 32 and 64 lanes per utterance; everything else runs the form that
-// reads beam and order from its arguments.  NSD_STEP_GENERIC=1 in the environment forces the latter (a debugging
-// aid: the two must give the same bits).
+// reads beam and order from its arguments.  The copy of the decoder without an EOS option (all hypotheses stay live)
+// takes the 4-lanes-per-row form there.  NSD_STEP_MODE in the environment restricts the choice (a debugging aid:
+// all forms must give the same bits): 0 = run-time form only, 1 = no 4-lanes-per-row form.
+template <int G, int VARIANT, int BT>
+static void launch_beam(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool quad)
+{
+    if constexpr (VARIANT == NSD_VARIANT_I) {
+        if (quad) return launch_gv<G, VARIANT, BT, 5, true>(a, p, N, s, ev0, ev1);
+    }
+    launch_gv<G, VARIANT, BT, 5, false>(a, p, N, s, ev0, ev1);
+}
+
 template <int G, int VARIANT>
 static void launch_shape(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    static const bool generic_only = [] { const char *e = getenv("NSD_STEP_GENERIC"); return e && e[0] == '1'; }();
+    static const int mode = [] { const char *e = getenv("NSD_STEP_MODE"); return e && e[0] >= '0' && e[0] <= '9' ? e[0] - '0' : 9; }();
     const bool lm5 = p.use_lm != 0 && a.tab.order == 5;
     if constexpr (G >= 32) {
-        if (lm5 && !generic_only) {
-            if (a.B == 16) return launch_gv<G, VARIANT, 16, 5>(a, p, N, s, ev0, ev1);
-            if (a.B == 8)  return launch_gv<G, VARIANT, 8, 5>(a, p, N, s, ev0, ev1);
-            if (a.B == 32) return launch_gv<G, VARIANT, 32, 5>(a, p, N, s, ev0, ev1);
+        if (lm5 && mode >= 1) {
+            const bool quad = mode >= 2;
+            if (a.B == 16) return launch_beam<G, VARIANT, 16>(a, p, N, s, ev0, ev1, quad);
+            if (a.B == 8)  return launch_beam<G, VARIANT, 8>(a, p, N, s, ev0, ev1, quad);
+            if (a.B == 32) return launch_beam<G, VARIANT, 32>(a, p, N, s, ev0, ev1, quad);
         }
     }
-    launch_gv<G, VARIANT, 0, -1>(a, p, N, s, ev0, ev1);
+    launch_gv<G, VARIANT, 0, -1, false>(a, p, N, s, ev0, ev1);
 }
 
 template <int VARIANT>

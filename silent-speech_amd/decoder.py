@@ -202,9 +202,7 @@ class NSDecoder:
         _lib.check(self.L.nsd_backtrace(C.byref(ws.ptrs), ws.backptr.data_ptr(), ws.token.data_ptr(),
                                         ws.T, ws.N, ws.B, ws.out_ids.data_ptr(), ws.out_len.data_ptr(),
                                         ws.out_score.data_ptr(), _stream_ptr()), "nsd_backtrace")
-        if ws.N and bool((ws.utt[:ws.N] & _lib.U_ERR_TOPK).any().item()):
-            raise RuntimeError("selected index k out of range (beam larger than the vocabulary in the "
-                               "top-k fall-back)")
+        self.raise_on_topk_error(ws)
         return ws.out_ids[:ws.N], ws.out_len[:ws.N], ws.out_score[:ws.N]
 
     # -- drivers -----------------------------------------------------------
@@ -262,7 +260,12 @@ class NSDecoder:
         return ws.out_ids[:ws.N], ws.out_len[:ws.N], ws.out_score[:ws.N]
 
     def raise_on_topk_error(self, ws: Workspace) -> None:
-        if ws.N and bool((ws.utt[:ws.N] & _lib.U_ERR_TOPK).any().item()):
+        if not ws.N:
+            return
+        bad = int((ws.utt[:ws.N] & (_lib.U_ERR_TOPK | _lib.U_ERR_INTERNAL)).max().item())
+        if bad & _lib.U_ERR_INTERNAL:
+            raise _lib.NsdError("nsd_step reported an overflowing candidate buffer (a defect of the library)")
+        if bad & _lib.U_ERR_TOPK:
             raise RuntimeError("selected index k out of range (beam larger than the vocabulary in the "
                                "top-k fall-back)")
 
@@ -356,6 +359,8 @@ def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, l
             logits[r] = v.to(dec.device)
         dec.step(ws, logits)
         um = int(ws.utt[0].item())
+        if um & _lib.U_ERR_INTERNAL:
+            raise _lib.NsdError("nsd_step reported an overflowing candidate buffer (a defect of the library)")
         if um & _lib.U_ERR_TOPK:
             raise RuntimeError("selected index k out of range")
         nb = um & 0xFF
