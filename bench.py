@@ -280,6 +280,197 @@ def secondary_variant(args, variant, words, corpus, tgd, tld, tg, tl):
                                            "algorithmic_bytes_per_launch")}}
 
 
+def cpu_ctc_rerank(words, corpus, targets, ctc_np, args, gpu_final, gpu_device_choice):
+    """inference_emg_llm.py:432-464 for one utterance at a time on one host core: the Python restatement of the
+    beam search, the frame argmax + collapse, postprocess of both transcripts and the LM choice; on a bounded
+    sample of the same utterances.  Also recomputes the choice without postprocess, which is what nsd_rerank_lm
+    takes on the device."""
+    import torch
+    from oracle import ns_oracle as O, synth
+    torch.set_num_threads(1)
+    TT = O.TextTransformLike
+    trie = O.build_trie(words)
+    lm = O.NgramLM(args.order, floor_vsz=(args.variant == "U")).fit(corpus)
+    n = min(args.cpu_utts, len(targets))
+    chars = mism = mism_dev = took_ctc = 0
+    t0 = time.perf_counter()
+    for u in range(n):
+        useed = synth.utt_seed(args.seed, args.utt0 + u)
+        tgt = synth.text_to_tokens(targets[u])
+        step_fn = lambda ids: torch.from_numpy(synth.logits_row(useed, ids, tgt, args.margin)).unsqueeze(0)
+        ids = O.constrained_beam_decode(step_fn, TT, args.beam, args.tmax, trie, lm, lm_weight=args.beta,
+                                        oov_penalty=args.gamma, variant=args.variant, word_bonus=args.kappa)
+        raw_ar = O.ids_to_text(TT, ids)
+        raw_ctc = O.ctc_hypothesis(ctc_np[u], TT)
+        hyp_ar = O.postprocess(raw_ar, trie, words)
+        hyp_ctc = O.postprocess(raw_ctc, trie, words)
+        hyp = O.rerank_lm(hyp_ar, hyp_ctc, lm)
+        chars += len(hyp)
+        took_ctc += int(hyp is hyp_ctc and hyp_ctc != hyp_ar)
+        mism += int(hyp != gpu_final[u])
+        mism_dev += int(O.rerank_lm(raw_ar, raw_ctc, lm) != gpu_device_choice[u])
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            n = u + 1
+            break
+    dt = time.perf_counter() - t0
+    return {"value": chars / dt, "unit": "chars/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} utterances of the same workload ({chars} final characters, {dt:.1f} s): Python "
+                      f"restatement of inference_emg_llm.py:432-464 (beam search, CTC argmax + collapse, postprocess, "
+                      f"LM choice), torch.set_num_threads(1)",
+            "ctc_transcript_chosen": took_ctc,
+            "final_transcript_mismatches_vs_gpu": mism,
+            "device_choice_mismatches_vs_restatement_without_postprocess": mism_dev}
+
+
+def ctc_rerank_workload(args, dev):
+    """The CTC proposal + rerank configuration on one GPU.  One step = AR decode of the batch (T_max scorer launches fed
+    by the synthetic AR head, back-trace), nsd_ctc_greedy over the resident (N, frames, 40) CTC logits and
+    nsd_rerank_lm, which scores both transcripts of every utterance with the n-gram tables and picks one
+    (inference_emg_llm.py:441-464 without the host-side postprocess).  The driver's complete tail, postprocess
+    included, is run once through transcribe_batch (host string work, timed separately) and compared with the CPU
+    restatement on the sampled utterances."""
+    from silent_speech_amd import TextTransform, synthetic as synth
+    from silent_speech_amd.decoder import (DeviceTables, NSDecoder, ctc_greedy_batch, ids_to_text, rerank_lm_batch,
+                                           transcribe_batch)
+    from silent_speech_amd.tables import NgramCounts
+    args.utt0 = 0
+    words, corpus, targets, tg, tl = build_workload(args.utts, 0, args.lex_words, args.corpus, args.order, False)
+    lm = NgramCounts(args.order, floor_vsz=(args.variant == "U")).fit(corpus)
+    tables = DeviceTables.from_words(words, lm)
+    dec = NSDecoder(tables, args.beam, args.tmax, variant=args.variant, lm_weight=args.beta, oov_penalty=args.gamma,
+                    word_bonus=args.kappa, lanes_per_utt=args.lanes)
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    ctc_np = synth.ctc_frame_logits(tg, tl, 0, args.ctc_frames, margin=args.ctc_margin)
+    ctc = torch.from_numpy(ctc_np).to(dev)
+    ws = dec.workspace(args.utts)
+    N, Tp = args.utts, args.ctc_frames
+
+    def one_step():
+        ids, lens, _ = dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=0, ws=ws)
+        ci, cl = ctc_greedy_batch(ctc)
+        choice, scores = rerank_lm_batch(tables, ids, lens, ci, cl)
+        return ids, lens, ci, cl, choice
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, lens, ci, cl, choice = one_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dec.raise_on_topk_error(ws)
+
+    ids_np, lens_np = ids.cpu().numpy(), lens.cpu().numpy()
+    ci_np, cl_np, ch_np = ci.cpu().numpy(), cl.cpu().numpy(), choice.cpu().numpy()
+    TT = TextTransform
+    picked = []
+    for u in range(N):
+        if ch_np[u]:
+            picked.append(ids_to_text(TT, [TT.BOS_IDX] + ci_np[u, :cl_np[u]].tolist() + [TT.EOS_IDX]))
+        else:
+            picked.append(ids_to_text(TT, ids_np[u, :lens_np[u]].tolist()))
+    chars = sum(len(s) for s in picked)
+    exact = sum(int(s == t) for s, t in zip(picked, targets))
+
+    # kernel durations: HIP events on the launch stream (torch's current stream is the one the library launches on)
+    def timed(fn, reps=20):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+    t_ctc = timed(lambda: ctc_greedy_batch(ctc))
+    t_rr = timed(lambda: rerank_lm_batch(tables, ids, lens, ci, cl))
+    ctc_bytes = float(N) * Tp * 160 + float(cl_np.sum()) + 4.0 * N
+    d = timed_launches(dec, ws, tgd, tld, args, args.timed_decodes)
+    T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, args)
+    roof = roofline_of(per_step, live, cands, d, ws.steps_run)
+    roof["traffic_note"] = "see profiles/ for the rocprofv3 passes of this command"
+
+    # the driver's complete tail once, postprocess (host, difflib) included
+    lex = set(words)
+    t1 = time.perf_counter()
+    final = transcribe_batch(TT, ids, lens, tables, lex.__contains__, words, ctc_logits=ctc)
+    t_tail = time.perf_counter() - t1
+
+    result = {
+        "metric": f"NS-decoded chars/sec (beam {args.beam}, trie+{args.order}-gram), CTC proposal + LM rerank",
+        "value": chars * args.steps / dt, "unit": "chars/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[3]: CTC-head proposals + NS rerank, {N} utterances, beam {args.beam}, closed "
+                               f"200-word template lexicon, char {args.order}-gram, variant {args.variant} "
+                               f"({VARIANT_SRC[args.variant]}) AR decode of T_max {args.tmax} + frame argmax / collapse "
+                               f"over ({N}, {Tp}, 40) CTC logits (planted target held 1-3 frames per character, "
+                               f"blanks, margin {args.ctc_margin} against noise in [-2, 2)) + LM choice between the "
+                               f"two transcripts (inference_emg_llm.py:441-464)",
+                   "parallelism": "one GPU",
+                   "chars_per_step": chars, "ctc_transcript_chosen": int(ch_np.sum()),
+                   "chosen_transcript_equals_target": exact,
+                   "value_counts": "characters of the transcript nsd_rerank_lm picks (ids_to_text of the AR ids or "
+                                   "of the collapsed CTC ids, no postprocess); the copy of the decoder without an "
+                                   "EOS option decodes all T_max steps, so an AR transcript runs past its target"},
+        "roofline": roof,
+        "ctc_greedy": {"kernel": "nsd_ctc_greedy_kernel", "bound": "hbm", "avg_launch_us": t_ctc * 1e6,
+                       "algorithmic_bytes_per_launch": ctc_bytes, "achieved": ctc_bytes / t_ctc / 1e9,
+                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ctc_bytes / t_ctc / 1e9 / HBM_PEAK_GBPS,
+                       "note": f"{ctc_bytes / 1e6:.0f} MB of logits per launch: below the 256 MB Infinity Cache, so "
+                               f"repeated launches over the same array may be served from it (events recorded around "
+                               f"the call include about 2 us of launch overhead)"},
+        "rerank_lm": {"kernel": "nsd_rerank_lm_kernel", "avg_launch_us": t_rr * 1e6},
+        "share_of_step": {"ar_decode_ms": 1e3 * dt / args.steps - 1e3 * (t_ctc + t_rr), "ctc_greedy_ms": 1e3 * t_ctc,
+                          "rerank_lm_ms": 1e3 * t_rr},
+        "final_transcripts": {"seconds": t_tail, "chars": sum(len(s) for s in final),
+                              "note": "transcribe_batch once: CTC argmax on the GPU, ids_to_text, postprocess (difflib "
+                                      "snap of out-of-lexicon words) and LM choice on the host, one core"},
+    }
+    if not args.no_cpu:
+        result["cpu_baseline"] = cpu_ctc_rerank(words, corpus, targets, ctc_np, args, final, picked)
+        result["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        result["speedup_vs_cpu_1core"] = result["value"] / result["cpu_baseline"]["value"]
+    return result
+
+
+def large_batch(args, words, corpus, n_utts, dev):
+    """The same decode at a batch that fills the GPU many times over (one GPU's share of the 1M-utterance
+    configuration): chars/s and the nsd_step roofline, with the fields of the main line."""
+    import copy
+    from silent_speech_amd import synthetic as synth
+    from silent_speech_amd.decoder import DeviceTables, NSDecoder
+    from silent_speech_amd.tables import NgramCounts
+    a2 = copy.copy(args)
+    a2.utts = n_utts
+    tg, tl = synth.pack_targets(synth.targets_for_range(words, a2.utt0, a2.utt0 + n_utts))
+    lm = NgramCounts(args.order, floor_vsz=(args.variant == "U")).fit(corpus)
+    dec = NSDecoder(DeviceTables.from_words(words, lm), args.beam, args.tmax, variant=args.variant,
+                    lm_weight=args.beta, oov_penalty=args.gamma, word_bonus=args.kappa, lanes_per_utt=args.lanes)
+    tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
+    ws = dec.workspace(n_utts)
+    reps = 3
+    dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=a2.utt0, ws=ws)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=a2.utt0, ws=ws)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dec.raise_on_topk_error(ws)
+    nchar, exact, starts = decoded_text_stats(ws.out_ids[:n_utts].cpu().numpy(), ws.out_len[:n_utts].cpu().numpy(),
+                                              tg, tl)
+    steps_run = ws.steps_run
+    d = timed_launches(dec, ws, tgd, tld, a2, 2)
+    T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, a2)
+    r = roofline_of(per_step, live, cands, d, steps_run)
+    return {"workload": f"{n_utts} utterances on one GPU, otherwise as the main line (variant {args.variant}, beam "
+                        f"{args.beam}, char {args.order}-gram, T_max {args.tmax})",
+            "value": float(nchar.sum()) * reps / dt, "unit": "chars/s", "decodes": reps,
+            "ms_per_decode": 1e3 * dt / reps, "chars_per_decode": int(nchar.sum()),
+            "targets_recovered_as_prefix": int(starts.sum()),
+            "target_chars_per_s": float(tl[starts].sum()) * reps / dt,
+            "roofline": r}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,6 +510,13 @@ def parse_args(argv=None):
                                                          "choice; 16, 32 or 64)")
     ap.add_argument("--lds-trie", type=int, default=0, help="node records of the upper trie levels every workgroup "
                                                             "stages in LDS (0 = none, the default)")
+    ap.add_argument("--large-utts", type=int, default=131072,
+                    help="utterances of the large_batch block measured after the main line on one GPU (0 = skip)")
+    ap.add_argument("--ctc-rerank", action="store_true",
+                    help="the CTC proposal + rerank configuration: AR decode, nsd_ctc_greedy over (N, frames, 40) CTC "
+                         "logits, nsd_rerank_lm (inference_emg_llm.py:441-464), one GPU")
+    ap.add_argument("--ctc-frames", type=int, default=256)
+    ap.add_argument("--ctc-margin", type=float, default=3.98)
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="seconds after which the self-started ranks of --gpus N are ended")
     return ap.parse_args(argv)
@@ -363,7 +561,10 @@ def worker(args):
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     import torch.distributed as dist
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group and the final gather run whatever the rank count, so that
+    # a one-rank torchrun line exercises the same RCCL calls as an eight-rank one
+    grouped = world > 1 or "WORLD_SIZE" in os.environ
+    if grouped:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -375,6 +576,13 @@ def worker(args):
     from silent_speech_amd.dist import gather_results, last_gathered, shard_range, unpack_gathered
     from silent_speech_amd.tables import NgramCounts
 
+    if args.ctc_rerank:
+        if grouped:
+            raise SystemExit("--ctc-rerank is a one-GPU workload")
+        result = ctc_rerank_workload(args, dev)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+        return
     if args.open_lexicon and args.lex_words == 200:
         args.lex_words = 100000
     strong = args.utts_total > 0
@@ -398,10 +606,10 @@ def worker(args):
         ids, lens, _ = dec.decode_synth_native(tgd, tld, base_seed=args.seed, margin=args.margin, utt0=args.utt0,
                                                check_every=args.check_every, ws=ws)
         # the exchange runs on every decode; rank 0 turns the receive buffer into (ids, lens) once, after the loop
-        gather_results(ids, lens, n_total, dst=0, unpack=False)
+        gather_results(ids, lens, n_total, dst=0, unpack=False, force=grouped)
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -414,7 +622,7 @@ def worker(args):
     fence()
     dt = time.perf_counter() - t0
     steps_run = ws.steps_run
-    if world > 1 and rank == 0:
+    if grouped and rank == 0:
         # the gathered block of rank 0 must be its own result
         per, width = (n_total + world - 1) // world, ws.out_ids.shape[1]
         g_ids, g_len = unpack_gathered(last_gathered(per, width, world, dev), n_total, width)
@@ -425,7 +633,7 @@ def worker(args):
             raise RuntimeError("gathered results differ from rank 0's own decode")
     rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # gloo reduces host tensors
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -437,11 +645,11 @@ def worker(args):
                          float(args.utts)], dtype=torch.float64, device=rdev)
     per_rank = torch.zeros(world, dtype=torch.float64, device=rdev)
     per_rank[rank] = float(args.utts)
-    if world > 1:
+    if grouped:
         dist.all_reduce(sums)
         dist.all_reduce(per_rank)
     if rank != 0:
-        if world > 1:
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -472,7 +680,8 @@ def worker(args):
                                f"variant {args.variant} ({VARIANT_SRC[args.variant]}), beta {args.beta}, gamma {args.gamma}, "
                                f"margin {args.margin}, T_max {args.tmax}",
                    "utterances_total": n_total, "utterances_per_rank": [int(x) for x in per_rank.tolist()],
-                   "ranks_reported_by_process_group": dist.get_world_size() if world > 1 else 1,
+                   "ranks_reported_by_process_group": dist.get_world_size() if grouped else 1,
+                   "process_group": (dist.get_backend() if grouped else None),
                    "parallelism": f"utterance-sharded x{world}, replicated tables",
                    "chars_per_decode": chars,
                    "targets_recovered_exactly": int(n_exact),
@@ -495,6 +704,9 @@ def worker(args):
                                               "command")
     if args.also and args.also != args.variant and world == 1:
         result["variant_" + args.also] = secondary_variant(args, args.also, words, corpus, tgd, tld, tg, tl)
+    if args.large_utts > args.utts and world == 1 and not args.open_lexicon:
+        del ws
+        result["large_batch"] = large_batch(args, words, corpus, args.large_utts, dev)
     if not args.no_cpu and world == 1:
         from silent_speech_amd.decoder import ids_to_text
         from silent_speech_amd import TextTransform
@@ -507,7 +719,7 @@ def worker(args):
         result["speedup_vs_cpu_1core"] = result["value"] / result["cpu_baseline"]["value"]
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(result) + "\n").encode())
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

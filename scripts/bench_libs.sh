@@ -7,7 +7,7 @@ for rep in 1 2; do
 for arg in "$@"; do
   so=${arg%%:*}; mode=${arg#*:}; [ "$mode" = "$arg" ] && mode=9
   tag=$(basename $so)_m$mode
-  NSD_STEP_MODE=$mode NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --no-cpu --also U > gpurun_out/b_$tag.log 2>gpurun_out/b_$tag.err || { tail -3 gpurun_out/b_$tag.err; exit 1; }
+  NSD_STEP_MODE=$mode NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --large-utts 0 --no-cpu --also U > gpurun_out/b_$tag.log 2>gpurun_out/b_$tag.err || { tail -3 gpurun_out/b_$tag.err; exit 1; }
   python - "$arg" gpurun_out/b_$tag.log <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for rep in 1 2; do
 for so in "$@"; do
-  NSDECODE_LIB=$PWD/$so timeout -k 10 300 python bench.py --no-cpu --utts 131072 --steps 4 --warmup 1 --timed-decodes 2 > gpurun_out/bb_$(basename $so).log 2>gpurun_out/bb_$(basename $so).err || { tail -3 gpurun_out/bb_$(basename $so).err; exit 1; }
+  NSDECODE_LIB=$PWD/$so timeout -k 10 300 python bench.py --large-utts 0 --no-cpu --utts 131072 --steps 4 --warmup 1 --timed-decodes 2 > gpurun_out/bb_$(basename $so).log 2>gpurun_out/bb_$(basename $so).err || { tail -3 gpurun_out/bb_$(basename $so).err; exit 1; }
   python - "$so" gpurun_out/bb_$(basename $so).log <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The three benchmark shapes only (no tests).  Usage: scripts/gpu_bench3.sh <tag>
 out=gpurun_out/$1; mkdir -p $out
-timeout -k 10 200 python bench.py --no-cpu > $out/default.json 2> $out/default.err || exit 1
-timeout -k 10 200 python bench.py --open-lexicon --beam 32 --no-cpu --steps 6 --also '' > $out/open32.json 2> $out/open32.err || exit 1
-timeout -k 10 200 python bench.py --no-cpu --utts 131072 --steps 5 --warmup 1 > $out/big.json 2> $out/big.err || exit 1
+timeout -k 10 200 python bench.py --large-utts 0 --no-cpu > $out/default.json 2> $out/default.err || exit 1
+timeout -k 10 200 python bench.py --large-utts 0 --open-lexicon --beam 32 --no-cpu --steps 6 --also '' > $out/open32.json 2> $out/open32.err || exit 1
+timeout -k 10 200 python bench.py --large-utts 0 --no-cpu --utts 131072 --steps 5 --warmup 1 > $out/big.json 2> $out/big.err || exit 1
 python - $out <<'PY'
 import json, sys
 for f in ("default", "open32", "big"):

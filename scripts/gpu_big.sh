@@ -4,7 +4,7 @@ tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out
 for arg in "$@"; do
   mode=${arg%%:*}; lanes=${arg#*:}
-  NSD_STEP_MODE=$mode timeout -k 10 200 python bench.py --no-cpu --utts 131072 --steps 5 --warmup 1 --also= --lanes $lanes > $out/big_m${mode}_l$lanes.json 2> $out/big_m${mode}_l$lanes.err || exit 1
+  NSD_STEP_MODE=$mode timeout -k 10 200 python bench.py --large-utts 0 --no-cpu --utts 131072 --steps 5 --warmup 1 --also= --lanes $lanes > $out/big_m${mode}_l$lanes.json 2> $out/big_m${mode}_l$lanes.err || exit 1
   python - $arg $out/big_m${mode}_l$lanes.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2])); b = d["roofline"]

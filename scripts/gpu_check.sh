@@ -8,9 +8,9 @@ echo "pytest rc=$rc"; tail -2 $out/pytest.log
 timeout -k 10 400 python scripts/fuzz_parity.py $nf 303 > $out/fuzz.log 2>&1; rc=$?
 echo "fuzz rc=$rc"; tail -1 $out/fuzz.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 200 python bench.py --no-cpu > $out/default.json 2> $out/default.err || exit 1
-timeout -k 10 200 python bench.py --open-lexicon --beam 32 --no-cpu --steps 6 > $out/open32.json 2> $out/open32.err || exit 1
-timeout -k 10 200 python bench.py --no-cpu --utts 131072 --steps 5 --warmup 1 > $out/big.json 2> $out/big.err || exit 1
+timeout -k 10 200 python bench.py --large-utts 0 --no-cpu > $out/default.json 2> $out/default.err || exit 1
+timeout -k 10 200 python bench.py --large-utts 0 --open-lexicon --beam 32 --no-cpu --steps 6 > $out/open32.json 2> $out/open32.err || exit 1
+timeout -k 10 200 python bench.py --large-utts 0 --no-cpu --utts 131072 --steps 5 --warmup 1 > $out/big.json 2> $out/big.err || exit 1
 python - $out <<'PY'
 import json, sys
 for f in ("default", "open32", "big"):

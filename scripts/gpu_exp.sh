@@ -17,8 +17,8 @@ for arg in "$@"; do
   so=${arg%%:*}; mode=${arg#*:}; [ "$mode" = "$arg" ] && mode=9
   t=$(basename $so)_m$mode
   export NSD_STEP_MODE=$mode
-  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --no-cpu --utts 131072 --steps 5 --warmup 1 --also= > $out/big_$t.json 2> $out/big_$t.err || exit 1
-  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --open-lexicon --beam 32 --no-cpu --steps 6 --also= > $out/open_$t.json 2> $out/open_$t.err || exit 1
+  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --large-utts 0 --no-cpu --utts 131072 --steps 5 --warmup 1 --also= > $out/big_$t.json 2> $out/big_$t.err || exit 1
+  NSDECODE_LIB=$PWD/$so timeout -k 10 200 python bench.py --large-utts 0 --open-lexicon --beam 32 --no-cpu --steps 6 --also= > $out/open_$t.json 2> $out/open_$t.err || exit 1
   python - $arg $out/big_$t.json $out/open_$t.json <<'PY'
 import json, sys
 b = json.load(open(sys.argv[2]))["roofline"]; o = json.load(open(sys.argv[3]))["roofline"]

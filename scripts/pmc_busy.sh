@@ -7,7 +7,7 @@ root=$PWD
 out=$root/gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --no-cpu --no-events --steps 3 --warmup 1 --also= $*"
+B="python3 $root/bench.py --large-utts 0 --no-cpu --no-events --steps 3 --warmup 1 --also= $*"
 timeout -s KILL 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY --output-format csv -d "$out/p1" -- $B > "$out/p1.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_WAVES --output-format csv -d "$out/p2" -- $B > "$out/p2.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 --output-format csv -d "$out/p3" -- $B > "$out/p3.log" 2>&1

@@ -11,7 +11,7 @@ tail -1 "$out/bench.log" > "$out/bench.json"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o s -- python3 "$root/bench.py" --no-cpu > "$out/stats.log" 2>&1
 rm -f "$out"/stats/*kernel_trace.csv
-B="python3 $root/bench.py --no-cpu --no-events --steps 4 --warmup 1 --also="
+B="python3 $root/bench.py --large-utts 0 --no-cpu --no-events --steps 4 --warmup 1 --also="
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- $B > "$out/pmc_fetch.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- $B > "$out/pmc_write.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_l2" -- $B > "$out/pmc_l2.log" 2>&1

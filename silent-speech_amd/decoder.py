@@ -276,18 +276,57 @@ class NSDecoder:
 _TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
+_DIGEST_LIMIT = 1 << 20          # dictionary entries / trie nodes a digest looks at
+
+
 def _fingerprint(trie, lm) -> tuple:
-    """Cheap signature of the objects' contents, so that an `lm.fit(...)` or `trie.insert(...)` on an object the
-    cache already knows is noticed (an O(1) check, not a proof: `clear_table_cache()` is the sure way)."""
-    t = (len(trie.next), bool(trie.end), tuple(sorted(map(str, trie.next)))[:40])
+    """Digest of the objects' contents, so that an `lm.fit(...)` or `trie.insert(...)` on an object the cache
+    already knows is noticed even when no size changes: the n-gram and context counts are summed, the trie's nodes
+    and word ends are counted (each over at most _DIGEST_LIMIT entries; beyond that `clear_table_cache()` is the
+    sure way).  Objects without the reference's attributes get a constant: building the tables then raises the
+    TypeError that names what is missing."""
+    from itertools import islice
+    nodes = ends = 0
+    stack = [trie]
+    while stack and nodes < _DIGEST_LIMIT:
+        nd = stack.pop()
+        nxt = getattr(nd, "next", None)
+        if not isinstance(nxt, dict):
+            break
+        nodes += 1
+        ends += 1 if getattr(nd, "end", False) else 0
+        stack.extend(nxt.values())
+    t = (nodes, ends)
     if lm is None:
         return t, None
-    return t, (int(lm.order), len(lm.counts), len(lm.context), len(lm.V))
+    counts, context = getattr(lm, "counts", None), getattr(lm, "context", None)
+    if not isinstance(counts, dict) or not isinstance(context, dict):
+        return t, ("?",)
+    return t, (int(getattr(lm, "order", 0)), len(counts), len(context), len(getattr(lm, "V", ())),
+               sum(islice(counts.values(), _DIGEST_LIMIT)), sum(islice(context.values(), _DIGEST_LIMIT)))
 
 
 def clear_table_cache() -> None:
-    """Forget the device tables built for earlier (trie, lm) objects."""
+    """Forget the device tables built for earlier (trie, lm) objects (and the one-utterance workspaces)."""
     _TABLE_CACHE.clear()
+    _WS_CACHE.clear()
+
+
+_WS_CACHE: "OrderedDict[tuple, Workspace]" = OrderedDict()
+
+
+def _workspace_for(dec: "NSDecoder") -> "Workspace":
+    """One-utterance workspace of the drop-in entry point, kept per (beam, steps, device): a call per utterance
+    re-initialises its 18 device buffers instead of allocating them again."""
+    key = (dec.B, dec.T, str(dec.device))
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+        ws = _WS_CACHE[key] = dec.workspace(1)
+        while len(_WS_CACHE) > 4:
+            _WS_CACHE.popitem(last=False)
+    else:
+        _WS_CACHE.move_to_end(key)
+    return ws
 
 
 def _tables_for(trie, lm, floor_vsz) -> DeviceTables:
@@ -331,7 +370,7 @@ def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, l
                     length_penalty_alpha=length_penalty_alpha, min_len_for_eos=min_len_for_eos,
                     use_lm=lm is not None)
     B = dec.B
-    ws = dec.workspace(1)
+    ws = _workspace_for(dec)
     dec.init(ws)
     hyps: List[List[int]] = [[BOS_ID]]
     # torch.topk(k=beam) of the reference's fall-back raises when beam exceeds the vocabulary (copies I and E,

@@ -53,18 +53,20 @@ def _buffers(per: int, width: int, world: int, device):
     return b
 
 
-def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int = 0, unpack: bool = True
-                   ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+def gather_results(ids: torch.Tensor, lens: torch.Tensor, n_total: int, dst: int = 0, unpack: bool = True,
+                   force: bool = False) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """Collect every rank's (ids u8 [n_r, T+1], lens i32 [n_r]) on `dst`, in utterance order.
 
     One padded all_gather (RCCL on GPUs, gloo on CPU); returns
     (ids [n_total, T+1], lens [n_total]) on dst and None elsewhere.  Without an
-    initialised process group the inputs are returned unchanged.  With
+    initialised process group, or with a group of one rank, the inputs are
+    returned unchanged; ``force=True`` runs the collective even in a group of one
+    rank (the result then comes out of the receive buffer like any other).  With
     ``unpack=False`` the exchange is enqueued and nothing is returned; `unpack_gathered`
     turns the receive buffer into the result later (a loop that only needs the
     last result does not pay for the others).
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return ids, lens
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_total + world - 1) // world

@@ -76,3 +76,36 @@ def pack_targets(targets: list[str]):
         cols = np.arange(flat.shape[0]) - np.repeat(starts, tl)
         tg[rows, cols] = flat.astype(np.int8)
     return tg, tl
+
+
+def ctc_frame_logits(tg: np.ndarray, tl: np.ndarray, utt0: int, frames: int = 256, seed: int = 7,
+                     margin: float = 3.98, sub_rate: float = 0.02) -> np.ndarray:
+    """Synthetic CTC-head output, float32 [N, frames, 40], for planted targets (int8 [N, S], int32 [N]).
+
+    Each target character is held for 1-3 frames, a blank (id 39, the CTC blank of train_emg_llm.py:239) separates
+    equal neighbours, 0-2 blanks follow every character, blanks fill the rest; with probability `sub_rate` a
+    character is replaced by a random one, so some proposals carry out-of-lexicon words.  Logits are uniform noise in
+    [-2, 2) plus `margin` on the frame's label: with a margin just below 4 a frame in a few hundred is won by
+    the noise.
+    One MT19937 stream per utterance of the global numbering (seed, utt0 + u), independent of the batch split."""
+    n = int(tl.shape[0])
+    out = np.empty((n, frames, 40), np.float32)
+    blank = 39
+    rows = np.arange(frames)
+    for u in range(n):
+        rng = np.random.RandomState((seed * 1000003 + utt0 + u) & 0x7FFFFFFF)
+        labels: list[int] = []
+        for c in tg[u, :int(tl[u])].tolist():
+            if rng.random_sample() < sub_rate:
+                c = int(rng.randint(0, 37))
+            if labels and labels[-1] == c:
+                labels.append(blank)
+            labels.extend([c] * int(rng.randint(1, 4)))
+            labels.extend([blank] * int(rng.randint(0, 3)))
+        lab = np.full(frames, blank, np.int64)
+        k = min(frames, len(labels))
+        lab[:k] = labels[:k]
+        x = ((rng.random_sample((frames, 40)) - 0.5) * 4.0).astype(np.float32)
+        x[rows, lab] += np.float32(margin)
+        out[u] = x
+    return out

@@ -85,13 +85,27 @@ def scored_cases():
                         n_words=200, lex_seed=0, min_len=2, max_len=8, n_corpus=20000, corpus_seed=1,
                         n_utts=32, target_seed=1001, min_words=2, max_words=5, base_seed=77,
                         margin=4.0, beta=0.1, gamma=1.0, kappa=0.35, alpha=0.6, min_len_for_eos=8))
-    # the random-access stress shape: 100 000 words over a-z0-9, beam 32 (few utterances: the reference walks a
-    # dict trie of that size per hypothesis and step)
+    # the random-access stress shape: 100 000 words over a-z0-9, beam 32 (the first, short cases)
     for v in ("U", "I", "E"):
         out.append(dict(name=f"open4_{v}_b32", variant=v, beam=32, lm_order=5, max_new_tokens=32,
                         n_words=100000, lex_seed=1, alphabet=synth.BASE_CHARS[:36], min_len=2, max_len=12,
                         n_corpus=20000, corpus_seed=1, n_utts=4, target_seed=1002, min_words=2, max_words=4,
                         base_seed=20260403, margin=60.0, beta=0.05, gamma=1.0, kappa=0.35, alpha=0.6,
+                        min_len_for_eos=8))
+    # the same shape at the benchmark's length: 32 utterances per copy, T 64
+    for v in ("U", "I", "E"):
+        out.append(dict(name=f"open32_{v}_b32", variant=v, beam=32, lm_order=5, max_new_tokens=64,
+                        n_words=100000, lex_seed=1, alphabet=synth.BASE_CHARS[:36], min_len=2, max_len=12,
+                        n_corpus=20000, corpus_seed=1, n_utts=32, target_seed=1003, min_words=3, max_words=7,
+                        base_seed=20260403, margin=60.0, beta=0.05, gamma=1.0, kappa=0.35, alpha=0.6,
+                        min_len_for_eos=8))
+    # ... and with a small margin on that lexicon: log-softmax values that carry fp32 rounding where most n-grams
+    # of a candidate are unseen
+    for v in ("U", "I", "E"):
+        out.append(dict(name=f"opensoft16_{v}_b32", variant=v, beam=32, lm_order=5, max_new_tokens=48,
+                        n_words=100000, lex_seed=1, alphabet=synth.BASE_CHARS[:36], min_len=2, max_len=12,
+                        n_corpus=20000, corpus_seed=1, n_utts=16, target_seed=1004, min_words=2, max_words=5,
+                        base_seed=78, margin=4.0, beta=0.1, gamma=1.0, kappa=0.35, alpha=0.6,
                         min_len_for_eos=8))
     return out
 

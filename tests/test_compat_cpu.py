@@ -27,3 +27,27 @@ def test_signatures_equal_the_reference_files():
                                                              ("min_len_for_eos", P.KEYWORD_ONLY, 8)]
     for m in (ns_utils, inference_emg_llm, eval_ar):
         assert callable(m.ids_to_text) and callable(m.postprocess)
+
+
+def test_table_cache_digest_sees_counts_and_inner_trie_nodes():
+    """The digest that keys the drop-in's table cache changes with a refit that keeps every dictionary size and
+    with a word inserted below an existing first letter; an object without counts gets a constant."""
+    from oracle import ns_oracle as O
+    from silent_speech_amd.decoder import _fingerprint
+    trie = O.build_trie(["ab", "ba"])
+    lm = O.NgramLM(2).fit(["ab ba ab ab ab ab ab"])
+    f0 = _fingerprint(trie, lm)
+    sizes = (len(lm.counts), len(lm.context), len(lm.V))
+    lm.fit(["ab ba ba ba ba ba ab"])
+    assert (len(lm.counts), len(lm.context), len(lm.V)) == sizes
+    f1 = _fingerprint(trie, lm)
+    assert f1 != f0 and f1[0] == f0[0]
+    trie.insert("aa")
+    f2 = _fingerprint(trie, lm)
+    assert f2[0] != f1[0] and f2[1] == f1[1]
+    assert _fingerprint(trie, None)[1] is None
+
+    class OnlyLogp:
+        def logp(self, s):
+            return 0.0
+    assert _fingerprint(trie, OnlyLogp())[1] == ("?",)

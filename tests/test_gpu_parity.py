@@ -134,6 +134,45 @@ def test_drop_in_notices_a_refitted_language_model(dev):
     assert a == want_a and b == want_b and want_a != want_b
 
 
+def test_drop_in_notices_a_same_size_refit_and_a_trie_insert(dev):
+    """A refit that changes counts but neither the set of n-grams nor any dictionary size, and a word inserted
+    under an existing first letter, both lead to new device tables (the reference reads the live objects)."""
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.compat import ns_utils
+    words = ["ab", "ba"]
+    trie = O.build_trie(words)
+    lm = O.NgramLM(2).fit(["ab ba ab ab ab ab ab"])
+    flat = lambda ids: torch.zeros(1, 40)                              # noqa: E731
+    run = lambda: ns_utils.constrained_beam_decode(flat, TextTransform, 2, 4, trie, lm, lm_weight=5.0,   # noqa: E731
+                                                   allow_eos_anytime=False)
+    want = lambda: O.constrained_beam_decode(flat, O.TextTransformLike, 2, 4, trie, lm, lm_weight=5.0,   # noqa: E731
+                                             allow_eos_anytime=False)
+    a, want_a = run(), want()
+    sizes = (len(lm.counts), len(lm.context), len(lm.V))
+    lm.fit(["ab ba ba ba ba ba ab"])
+    assert (len(lm.counts), len(lm.context), len(lm.V)) == sizes
+    b, want_b = run(), want()
+    assert a == want_a and b == want_b and want_a != want_b
+    lm.fit(["aa"] * 30)                                                # (fit adds to the counts it has)
+    c, want_c = run(), want()
+    trie.insert("aa")                                                  # the root's children stay {a, b}
+    d, want_d = run(), want()
+    assert c == want_c and d == want_d and want_d != want_c
+
+
+def test_drop_in_rejects_a_model_without_counts(dev):
+    """A KenLM-style object (only .logp) is refused by name, before anything is decoded."""
+    from silent_speech_amd import TextTransform
+    from silent_speech_amd.compat import ns_utils
+
+    class OnlyLogp:
+        def logp(self, s):
+            return 0.0
+    with pytest.raises(TypeError, match="KenLM"):
+        ns_utils.constrained_beam_decode(lambda ids: torch.zeros(1, 40), TextTransform, 2, 3, O.build_trie(["ab"]),
+                                         OnlyLogp())
+
+
 def _run_case_batched(case, dev, with_masks=True):
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
     words = case_words(case)
