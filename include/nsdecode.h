@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NSD_VERSION        102
+#define NSD_VERSION        103
 #define NSD_V              40
 #define NSD_NBASE          37
 #define NSD_SPACE          36
@@ -51,10 +51,11 @@ extern "C" {
 #define NSD_E_BEAM         -2   /* beam outside [1, NSD_MAX_BEAM] */
 #define NSD_E_VOCAB        -3   /* V != NSD_V */
 #define NSD_E_ORDER        -4   /* n-gram order outside [0, NSD_MAX_ORDER] */
-#define NSD_E_TABLE        -5   /* malformed table (capacity not a power of two, empty trie, ...) */
+#define NSD_E_TABLE        -5   /* malformed table (capacity not a power of two, empty trie, a log-prob that is not finite, ...) */
 #define NSD_E_VARIANT      -6
 #define NSD_E_SIZE         -7   /* negative / oversized count */
 #define NSD_E_NOALLOC_SIZE -8   /* batch larger than the built-in scratch of nsd_decode_synth_noalloc */
+#define NSD_E_ALIGN        -9   /* a row pointer of the AR-step kernels is not a multiple of 16 bytes */
 
 /* beam flags (low byte of NsdBeamState.meta) */
 #define NSD_F_FINISHED      1u  /* last token is EOS */
@@ -330,7 +331,9 @@ int nsd_kv_reorder(const void *src, void *dst, const uint8_t *backptr, int32_t L
  * hipBLASLt, these kernels are what lies between them.  The generated keys / values are never moved: position s
  * of the generated part is a slab [M, kv_heads, hd] written once (M = N*B hypotheses), and hypothesis m reads,
  * at position s, the slab row of its ancestor at that step, found through the scorer's back-pointers.
- * Element type of activations, weights and caches: dtype 0 = fp32, 1 = bf16; arithmetic in fp32. */
+ * Element type of activations, weights and caches: dtype 0 = fp32, 1 = bf16; arithmetic in fp32.
+ * nsd_add_rmsnorm, nsd_swiglu, nsd_attn_step and nsd_attn_ctx move rows in 16-byte pieces: every array pointer
+ * must be a multiple of 16 bytes (a tensor view with a storage offset may not be), else NSD_E_ALIGN. */
 
 /* anc[s, m] (u8 [>= t, M]) = in-beam rank of the hypothesis that hypothesis m (of the beam after scorer step
  * t-1) descends from at generated position s < t.   backptr device [>= t, M] as written by nsd_step. */
@@ -364,7 +367,9 @@ int nsd_attn_step(const void *q, const void *kctx, const void *vctx, const void 
  * query heads of a kv head share the context keys, so scores and weighted sums are small dense products
  * (v_mfma_f32_16x16x32_bf16).  kctx_pad [N, kv_heads, S32, hd]: context keys, rows S..S32-1 zero; vctx_t
  * [N, kv_heads, hd, S32]: context values transposed (keys contiguous), columns S..S32-1 zero; S32 a multiple of
- * 32, at most 256; hd 64 or 128.  Leaves per query row the unnormalised weighted value sum, the maximum and the
+ * 32, at most 256; hd 64 or 128.  The zero padding is a precondition the caller must establish: padded keys are
+ * masked out of the softmax, but padded value columns are multiplied by a weight of 0, so an Inf or NaN left
+ * there turns whole output rows into NaN.  Leaves per query row the unnormalised weighted value sum, the maximum and the
  * sum of the weights (part_o fp32 [M*heads, hd], part_m / part_l fp32 [M*heads]) for nsd_attn_step to continue. */
 int nsd_attn_ctx(const void *q, const void *kctx_pad, const void *vctx_t, int32_t N, int32_t B, int32_t heads,
                  int32_t kvh, int32_t hd, int32_t S, int32_t S32, float scale, float *part_o, float *part_m,
@@ -416,7 +421,11 @@ int nsd_decode_synth(const NsdTables *t, const NsdParams *p, const NsdBeamState 
  * logits rows and the back-pointer / token arrays live in a scratch array built into the library
  * (NSD_NOALLOC_SCRATCH_BYTES of device memory on every GPU the library runs on, held until the process ends);
  * the caller passes only the inputs (tables, parameters, targets) and the outputs.  The call allocates
- * nothing and does not synchronise.
+ * nothing and does not synchronise.  The array's device address is looked up once per GPU by nsd_tables_create
+ * (which a caller has run on that GPU anyway to get `t`, outside any capture); a call on a GPU where no tables
+ * were ever created looks it up itself.  What the HIP runtime does the first time a process launches a kernel
+ * (loading the library's code objects) is outside the library's hands: make one warm-up call, or any other decode
+ * through the library, before the first call that must not allocate (e.g. before a capture begins).
  *   limits   N * B <= NSD_NOALLOC_MAX_HYPS and N * B * T <= NSD_NOALLOC_MAX_CELLS, else NSD_E_NOALLOC_SIZE
  *   sharing  all calls on one GPU use that GPU's one array: calls that overlap on a GPU (two streams, two
  *            threads) race; calls on one stream, or ordered by events, are fine */

@@ -11,10 +11,14 @@ sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 from silent_speech_amd import build as B, lib
 
-so = ROOT / "gpurun_out" / "libnsdecode_stamps.so"
-so.parent.mkdir(exist_ok=True)
-cmd = [B.hipcc(), *B.FLAGS, "-DNSD_STAMPS", f"-I{ROOT/'include'}", f"-I{B.CSRC}", *[str(B.CSRC / s) for s in B.SOURCES], "-o", str(so)]
-subprocess.run(cmd, check=True)
+so = ROOT / "silent-speech_amd" / "libnsdecode_stamps.so"
+if len(sys.argv) > 1 and sys.argv[1] == "--build":      # on the CPU box, before the GPU call
+    cmd = [B.hipcc(), *B.FLAGS, "-DNSD_STAMPS", f"-I{ROOT/'include'}", f"-I{B.CSRC}", *[str(B.CSRC / s) for s in B.SOURCES], "-o", str(so)]
+    subprocess.run(cmd, check=True)
+    print("built", so)
+    sys.exit(0)
+if not so.exists():
+    raise SystemExit(f"{so} is missing: run `python scripts/phase_profile.py --build` first")
 lib.SO_PATH = so
 from silent_speech_amd.decoder import DeviceTables, NSDecoder
 from silent_speech_amd import synthetic as S

@@ -688,12 +688,17 @@ extern "C" int nsd_ancestors(const uint8_t *backptr, int32_t t, int32_t N, int32
     return (int)hipGetLastError();
 }
 
+// every pointer given is a multiple of 16 (null pointers pass): the kernels move rows in 16-byte pieces
+template <class... P>
+static bool aligned16(P... p) { return ((((uintptr_t)p) | ...) & 15u) == 0; }
+
 extern "C" int nsd_add_rmsnorm(const void *x, const void *delta, const void *w, float eps, int32_t rows, int32_t hidden,
                                int32_t dtype, void *x_out, void *h, void *stream)
 {
     if (rows < 0 || hidden < 1 || (dtype != 0 && dtype != 1) || hidden % (dtype ? 8 : 4)) return NSD_E_SIZE;
     if (rows == 0) return NSD_OK;
     if (!x || !w || !h || (delta && !x_out)) return NSD_E_NULL;
+    if (!aligned16(x, delta, w, x_out, h)) return NSD_E_ALIGN;
     if (dtype == 0)
         launch_add_rmsnorm<float>((const float *)x, (const float *)delta, (const float *)w, eps, rows, hidden,
                                   (float *)x_out, (float *)h, (hipStream_t)stream);
@@ -739,6 +744,7 @@ extern "C" int nsd_swiglu(const void *gate_up, int64_t rows, int32_t inter, int3
     if (rows < 0 || inter < 1 || (dtype != 0 && dtype != 1) || inter % (dtype ? 8 : 4)) return NSD_E_SIZE;
     if (rows == 0) return NSD_OK;
     if (!gate_up || !out) return NSD_E_NULL;
+    if (!aligned16(gate_up, out)) return NSD_E_ALIGN;
     const long long n = rows * (inter / (dtype ? 8 : 4));
     if ((n + 255) / 256 > 0x7fffffffll) return NSD_E_SIZE;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -760,6 +766,7 @@ extern "C" int nsd_attn_ctx(const void *q, const void *kctx_pad, const void *vct
         return NSD_E_SIZE;
     if (N == 0) return NSD_OK;
     if (!q || !kctx_pad || !vctx_t || !part_o || !part_m || !part_l) return NSD_E_NULL;
+    if (!aligned16(q, kctx_pad, vctx_t, part_o)) return NSD_E_ALIGN;
     CtxArgs a;
     a.q = (const BF16 *)q; a.kpad = (const BF16 *)kctx_pad; a.vt = (const BF16 *)vctx_t;
     a.po = part_o; a.pm = part_m; a.pl = part_l;
@@ -783,6 +790,7 @@ extern "C" int nsd_attn_step(const void *q, const void *kctx, const void *vctx, 
     const bool part = part_o != nullptr;
     if (part && (!part_m || !part_l)) return NSD_E_NULL;
     if (!q || !kgen || !vgen || !out || (S > 0 && !part && (!kctx || !vctx)) || (t > 0 && !anc)) return NSD_E_NULL;
+    if (!aligned16(q, kctx, vctx, kgen, vgen, out, part_o)) return NSD_E_ALIGN;
     AttnArgs a;
     a.part_o = part_o; a.part_m = part_m; a.part_l = part_l;
     a.q = q; a.kctx = kctx; a.vctx = vctx; a.kgen = kgen; a.vgen = vgen; a.anc = anc; a.out = out;

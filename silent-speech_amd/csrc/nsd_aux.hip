@@ -24,6 +24,7 @@ extern "C" const char *nsd_strerror(int code)
     case NSD_E_SIZE:    return "size argument out of range";
     case NSD_E_NOALLOC_SIZE: return "batch exceeds the built-in scratch of nsd_decode_synth_noalloc "
                                     "(N*B <= 65536 and N*B*T <= 4194304)";
+    case NSD_E_ALIGN:   return "array pointer not a multiple of 16 bytes";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -37,12 +38,22 @@ extern "C" uint64_t nsd_hash64(uint64_t key) { return nsd_mix64(key); }
 // ---------------------------------------------------------------------
 static bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
 
+static int nsd_scratch_address(unsigned char **out);
+
 extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm, NsdTables **out)
 {
     if (!trie || !out || !trie->nodes) return NSD_E_NULL;
     if (trie->n_nodes < 1) return NSD_E_TABLE;
     const int order = lm ? lm->order : 0;
     if (order < 0 || order > NSD_MAX_ORDER) return NSD_E_ORDER;
+    {   // The library's set-up call also resolves this device's address of the built-in scratch array (the first
+        // look-up of a device symbol loads the code object and may allocate): nsd_decode_synth_noalloc then finds
+        // it in the per-device cache and calls nothing that allocates, from its first call on.
+        unsigned char *sp = nullptr;
+        const int rc = nsd_scratch_address(&sp);
+        if (rc != NSD_OK) return rc;
+    }
+    double lo = 0.0, hi = 0.0;                     // range of the values a table look-up can return
     if (order > 0) {
         if (!lm->grams || !lm->ctxs) return NSD_E_NULL;
         if (!is_pow2(lm->gram_cap) || !is_pow2(lm->ctx_cap) || lm->ctx_cap > (1ull << 32)) return NSD_E_TABLE;
@@ -64,6 +75,20 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
             if (lm->ctxs[i].ctx_id >= lm->n_ctx_recs) return NSD_E_TABLE;
         }
         if (lm->init_ctx != NSD_CTX_NONE && lm->init_ctx >= lm->n_ctx_recs) return NSD_E_TABLE;
+        {   // Range of the values a look-up can return: the bounds of a candidate's score before its look-up are
+            // built from it, so every log-prob must be a finite number (a NaN would lie outside any range and a
+            // bound that ignores it could drop a candidate that belongs to the top-B).
+            bool finite = __builtin_isfinite(lm->unseen);
+            lo = hi = lm->unseen;
+            auto see = [&](double v) { finite = finite && __builtin_isfinite(v); if (v < lo) lo = v; if (v > hi) hi = v; };
+            for (uint64_t i = 0; i < lm->gram_cap; ++i)
+                if (lm->grams[i].key != NSD_KEY_EMPTY) see(lm->grams[i].logp);
+            for (uint64_t i = 0; i < lm->ctx_cap; ++i)
+                if (lm->ctxs[i].key != NSD_KEY_EMPTY) { see(lm->ctxs[i].backoff); see(lm->ctxs[i].term); }
+            for (uint32_t i = 0; i < lm->n_ctx_recs; ++i) { see(lm->ctx_recs[i].backoff); see(lm->ctx_recs[i].term); }
+            for (uint32_t i = 0; i < lm->n_gram_recs; ++i) { see(lm->gram_recs[i].logp); see(lm->gram_recs[i].term_next); }
+            if (!finite) return NSD_E_TABLE;
+        }
     }
     // children of every node must stay inside the array
     for (uint32_t i = 0; i < trie->n_nodes; ++i) {
@@ -114,18 +139,8 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
                 if (lm->grams[h].key == NSD_KEY_EMPTY) break;
             }
         }
-        {   // range of the values a look-up can return (bounds of a candidate's score before its look-up)
-            double lo = lm->unseen, hi = lm->unseen;
-            auto see = [&](double v) { if (v < lo) lo = v; if (v > hi) hi = v; };
-            for (uint64_t i = 0; i < lm->gram_cap; ++i)
-                if (lm->grams[i].key != NSD_KEY_EMPTY) see(lm->grams[i].logp);
-            for (uint64_t i = 0; i < lm->ctx_cap; ++i)
-                if (lm->ctxs[i].key != NSD_KEY_EMPTY) { see(lm->ctxs[i].backoff); see(lm->ctxs[i].term); }
-            for (uint32_t i = 0; i < lm->n_ctx_recs; ++i) { see(lm->ctx_recs[i].backoff); see(lm->ctx_recs[i].term); }
-            for (uint32_t i = 0; i < lm->n_gram_recs; ++i) { see(lm->gram_recs[i].logp); see(lm->gram_recs[i].term_next); }
-            t->min_logp = lo;
-            t->max_logp = hi;
-        }
+        t->min_logp = lo;
+        t->max_logp = hi;
         t->gram_mask = lm->gram_cap - 1;
         t->ctx_mask = lm->ctx_cap - 1;
         t->unseen = lm->unseen;
@@ -331,7 +346,78 @@ extern "C" int nsd_ctc_greedy(const float *logits, int32_t N, int32_t Tp, int32_
 // whole-string LM score: sum over the windows of '^' + strip(text) + '$',
 // left to right (the summation order of CharNgramLM.logp)
 // ---------------------------------------------------------------------
-__global__ void nsd_lm_logp_kernel(NsdTables tab, const uint8_t *text, const int32_t *len, int N, int stride, double *out)
+// One wave scores one string.  text[0, len) are the base-character ids of the stripped text, in LDS.  Every lane
+// takes one window of a round of 64 (its context key is rebuilt from the order-1 symbols before it), so the table
+// probes of a round are in flight together; lane 0 then adds the round's values in text order.  The result is
+// valid on lane 0.
+NSD_D double nsd_wave_logp(const NsdTables &tab, const uint8_t *text, int len, double *vals, int lane)
+{
+    const int order = tab.order;
+    const int m = len + 2;                         // symbols in '^' + text + '$'
+    auto sym_at = [&](int p) -> uint32_t {
+        return p == 0 ? NSD_SYM_HAT : (p == m - 1 ? NSD_SYM_DOLLAR : (uint32_t)text[p - 1] + 1u);
+    };
+    double lp = 0.0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        double v = 0.0;
+        if (i < m && i + 1 >= order) {             // window ending at symbol i exists
+            uint64_t ctx = 0;
+            for (int k = order - 1; k >= 1; --k)
+                if (i - k >= 0) ctx = (ctx << 6) | sym_at(i - k);
+            if (!nsd_gram_find(tab, (ctx << 6) | sym_at(i), v)) v = nsd_ctx_backoff(tab, ctx);
+        }
+        vals[lane] = v;
+        nsd_wave_sync();
+        if (lane == 0) {
+            const int cnt = m - i0 < 64 ? m - i0 : 64;
+            for (int q = 0; q < cnt; ++q)
+                if (i0 + q + 1 >= order) lp += vals[q];
+        }
+        nsd_wave_sync();
+    }
+    return lp;
+}
+
+// first and last non-space position of buf[0, k) (LDS), -1 when there is none; uniform over the wave
+NSD_D void nsd_wave_strip(const uint8_t *buf, int k, int lane, int &first, int &last)
+{
+    first = last = -1;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int j = j0 + lane;
+        const uint64_t nsb = __builtin_amdgcn_ballot_w64(j < k && buf[j] != NSD_SPACE);
+        if (nsb) {
+            if (first < 0) first = j0 + __ffsll((long long)nsb) - 1;
+            last = j0 + 63 - __clzll((long long)nsb);
+        }
+    }
+}
+
+constexpr int LM_WAVE_MAX_STRIDE = 16384;           // longest string the wave-per-string kernels stage in LDS
+
+__global__ void __launch_bounds__(256)
+nsd_lm_logp_kernel(NsdTables tab, const uint8_t *text, const int32_t *len, int N, int stride, int buf_bytes, double *out)
+{
+    extern __shared__ __align__(16) unsigned char lm_smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int u = blockIdx.x * (blockDim.x >> 6) + wid;
+    if (u >= N) return;
+    double *vals = reinterpret_cast<double *>(lm_smem + (size_t)wid * (512 + buf_bytes));
+    uint8_t *buf = reinterpret_cast<uint8_t *>(vals + 64);
+    const uint8_t *s = text + (size_t)u * stride;
+    const int b = len[u];
+    for (int i = lane; i < b; i += 64) buf[i] = s[i];
+    nsd_wave_sync();
+    if (b == 0) { if (lane == 0) out[u] = -1e9; return; }
+    int first, last;
+    nsd_wave_strip(buf, b, lane, first, last);
+    const int n = first < 0 ? 0 : last - first + 1;          // a text of spaces only scores "^$"
+    const double lp = nsd_wave_logp(tab, buf + (first < 0 ? 0 : first), n, vals, lane);
+    if (lane == 0) out[u] = lp;
+}
+
+// the same with one lane per string: strings too long to stage in LDS
+__global__ void nsd_lm_logp_serial_kernel(NsdTables tab, const uint8_t *text, const int32_t *len, int N, int stride, double *out)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= N) return;
@@ -364,13 +450,72 @@ extern "C" int nsd_lm_logp(const NsdTables *t, const uint8_t *text, const int32_
     if (N < 0 || stride < 0) return NSD_E_SIZE;
     if (N == 0) return NSD_OK;
     if (!text || !len || !out) return NSD_E_NULL;
-    hipLaunchKernelGGL(nsd_lm_logp_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                       *t, text, len, N, stride, out);
+    if (stride > LM_WAVE_MAX_STRIDE) {
+        hipLaunchKernelGGL(nsd_lm_logp_serial_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                           *t, text, len, N, stride, out);
+    } else {
+        const int buf_bytes = (stride + 15) & ~15;
+        const int waves = buf_bytes > 8192 ? 1 : 4;
+        hipLaunchKernelGGL(nsd_lm_logp_kernel, dim3((N + waves - 1) / waves), dim3(64 * waves),
+                           (size_t)waves * (512 + buf_bytes), (hipStream_t)stream, *t, text, len, N, stride, buf_bytes, out);
+    }
     return (int)hipGetLastError();
 }
 
 // lm.logp(text) - 0.002 * len(text) of the text that ids_to_text would produce from `ids`
-// (scripts/ns_utils.py:284-296): optional leading BOS skipped, stop at EOS, ids >= 37 dropped, stripped
+// (scripts/ns_utils.py:284-296): optional leading BOS skipped, stop at EOS, ids >= 37 dropped, stripped.
+// One wave per string: the kept characters are compacted into `buf` (LDS, room for n bytes) chunk by chunk,
+// stripped, and scored by nsd_wave_logp.  Valid on lane 0.
+NSD_D double nsd_wave_hyp_lm_score(const NsdTables &tab, const uint8_t *ids, int n, bool skip_first, uint8_t *buf,
+                                   double *vals, int lane)
+{
+    int k = 0;
+    for (int i0 = skip_first ? 1 : 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t c = i < n ? ids[i] : 0xffu;
+        const uint64_t eos = __builtin_amdgcn_ballot_w64(i < n && c == NSD_EOS);
+        const int limit = eos ? __ffsll((long long)eos) - 1 : 64;          // lanes from the first EOS on are out
+        const bool keep = i < n && lane < limit && c < NSD_NBASE;
+        const uint64_t kb = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) buf[k + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u))] = (uint8_t)c;
+        k += __popcll(kb);
+        if (eos) break;
+    }
+    nsd_wave_sync();
+    if (k == 0) return -1e9;                       // empty string: CharNgramLM returns -1e9
+    int first, last;
+    nsd_wave_strip(buf, k, lane, first, last);
+    // a text of spaces only is not empty for logp (it scores "^$"), but ids_to_text has already stripped it,
+    // so logp sees "" -> -1e9
+    if (first < 0) return -1e9;
+    const int len = last - first + 1;
+    return nsd_wave_logp(tab, buf + first, len, vals, lane) - 0.002 * (double)len;
+}
+
+// one workgroup of two waves per utterance: wave 0 scores the AR transcript, wave 1 the CTC proposal
+__global__ void __launch_bounds__(128)
+nsd_rerank_lm_kernel(NsdTables tab, const uint8_t *ar_ids, const int32_t *ar_len, int ar_stride,
+                     const uint8_t *ctc_ids, const int32_t *ctc_len, int ctc_stride,
+                     int N, int buf_bytes, uint8_t *choice, double *scores)
+{
+    extern __shared__ __align__(16) unsigned char lm_smem[];
+    __shared__ double both[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int u = blockIdx.x;
+    double *vals = reinterpret_cast<double *>(lm_smem + (size_t)wid * (512 + buf_bytes));
+    uint8_t *buf = reinterpret_cast<uint8_t *>(vals + 64);
+    const double sc = wid == 0
+        ? nsd_wave_hyp_lm_score(tab, ar_ids + (size_t)u * ar_stride, ar_len[u], true, buf, vals, lane)
+        : nsd_wave_hyp_lm_score(tab, ctc_ids + (size_t)u * ctc_stride, ctc_len[u], false, buf, vals, lane);
+    if (lane == 0) both[wid] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        choice[u] = both[1] > both[0] ? 1 : 0;     // max() keeps the first (AR) on ties
+        if (scores) { scores[2 * (size_t)u] = both[0]; scores[2 * (size_t)u + 1] = both[1]; }
+    }
+}
+
+// the same with one lane per utterance: strings too long to stage in LDS
 __device__ double nsd_hyp_lm_score(const NsdTables &tab, const uint8_t *ids, int n, bool skip_first)
 {
     // pass 1: bounds of the stripped text in the filtered character stream
@@ -382,10 +527,8 @@ __device__ double nsd_hyp_lm_score(const NsdTables &tab, const uint8_t *ids, int
         if (c != NSD_SPACE) { if (first < 0) first = k; last = k; }
         ++k;
     }
-    if (k == 0) return -1e9;                       // empty string before strip: CharNgramLM returns -1e9
+    if (k == 0) return -1e9;
     const int len = first < 0 ? 0 : last - first + 1;
-    // note: a text of spaces only is not empty for logp (it scores "^$"), but strip() makes len(s) = 0
-    // and ids_to_text has already stripped it, so logp sees "" -> -1e9
     if (len == 0) return -1e9;
     const int order = tab.order;
     double lp = 0.0;
@@ -413,9 +556,9 @@ __device__ double nsd_hyp_lm_score(const NsdTables &tab, const uint8_t *ids, int
     return lp - 0.002 * (double)len;
 }
 
-__global__ void nsd_rerank_lm_kernel(NsdTables tab, const uint8_t *ar_ids, const int32_t *ar_len, int ar_stride,
-                                     const uint8_t *ctc_ids, const int32_t *ctc_len, int ctc_stride,
-                                     int N, uint8_t *choice, double *scores)
+__global__ void nsd_rerank_lm_serial_kernel(NsdTables tab, const uint8_t *ar_ids, const int32_t *ar_len, int ar_stride,
+                                            const uint8_t *ctc_ids, const int32_t *ctc_len, int ctc_stride,
+                                            int N, uint8_t *choice, double *scores)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= N) return;
@@ -434,8 +577,16 @@ extern "C" int nsd_rerank_lm(const NsdTables *t, const uint8_t *ar_ids, const in
     if (N < 0 || ar_stride < 0 || ctc_stride < 0) return NSD_E_SIZE;
     if (N == 0) return NSD_OK;
     if (!ar_ids || !ar_len || !ctc_ids || !ctc_len || !choice) return NSD_E_NULL;
-    hipLaunchKernelGGL(nsd_rerank_lm_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                       *t, ar_ids, ar_len, ar_stride, ctc_ids, ctc_len, ctc_stride, N, choice, scores);
+    const int longest = ar_stride > ctc_stride ? ar_stride : ctc_stride;
+    if (longest > LM_WAVE_MAX_STRIDE) {
+        hipLaunchKernelGGL(nsd_rerank_lm_serial_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                           *t, ar_ids, ar_len, ar_stride, ctc_ids, ctc_len, ctc_stride, N, choice, scores);
+    } else {
+        const int buf_bytes = (longest + 15) & ~15;
+        hipLaunchKernelGGL(nsd_rerank_lm_kernel, dim3((unsigned)N), dim3(128), (size_t)2 * (512 + buf_bytes),
+                           (hipStream_t)stream, *t, ar_ids, ar_len, ar_stride, ctc_ids, ctc_len, ctc_stride, N,
+                           buf_bytes, choice, scores);
+    }
     return (int)hipGetLastError();
 }
 

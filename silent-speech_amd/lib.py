@@ -20,6 +20,7 @@ MAX_STEPS = 128
 TOKEN_CARRY = 0xFF
 U_DONE, U_ERR_TOPK, U_ERR_INTERNAL, U_STEPS_SHIFT = 0x100, 0x200, 0x400, 16
 F_FINISHED, F_DEAD, F_PENDING_SPACE = 1, 2, 4
+E_ALIGN = -9
 VARIANTS = {"U": 0, "I": 1, "E": 2}
 PRIOR_FORMS = {"U": 0, "T": 1}
 

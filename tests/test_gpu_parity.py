@@ -403,6 +403,84 @@ def test_lm_logp_and_rerank(dev):
         assert float(got[u]).hex() == tot.hex(), u
 
 
+def test_lm_scores_of_long_strings_on_both_kernel_forms(dev):
+    """Strings longer than one round of 64 windows, with leading / trailing / inner spaces, through nsd_lm_logp and
+    nsd_rerank_lm: the wave-per-string kernels (strings staged in LDS) and the one-lane-per-string kernels the
+    library takes beyond 16 384 bytes per row; bit-equal to CharNgramLM.logp."""
+    from silent_speech_amd import TextTransform as TT
+    from silent_speech_amd.decoder import DeviceTables, lm_logp_batch, rerank_lm_batch
+    words = synth.make_lexicon(80, 12, max_len=7)
+    corpus = synth.make_sentences(words, 400, 6)
+    rng = np.random.RandomState(8)
+    texts = []
+    for n in (63, 64, 65, 127, 128, 129, 200, 333):
+        t = " ".join(corpus[int(i)] for i in rng.randint(0, len(corpus), 40))
+        texts += [t[:n], "  " + t[:n - 4] + "  ", t[3:3 + n]]
+    texts += ["", "   ", "a"]
+    for order in (1, 3, 5):
+        lm = O.NgramLM(order).fit(corpus)
+        tables = DeviceTables.from_words(words, lm)
+        for S in (max(len(t) for t in texts), 16400):
+            ids = np.zeros((len(texts), S), np.uint8)
+            lens = np.array([len(t) for t in texts], np.int32)
+            for i, t in enumerate(texts):
+                ids[i, :len(t)] = synth.text_to_tokens(t)
+            got = lm_logp_batch(tables, torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)).cpu().numpy()
+            for i, t in enumerate(texts):
+                assert float(got[i]).hex() == lm.logp(t).hex(), (order, S, i)
+            # the same strings as decoded ids: BOS first, an EOS and a PAD inside, garbage after the EOS
+            ar = np.full((len(texts), S + 8), TT.PAD_IDX, np.uint8)
+            al = np.zeros(len(texts), np.int32)
+            for i, t in enumerate(texts):
+                row = [TT.BOS_IDX] + synth.text_to_tokens(t)[:len(t) // 2] + [TT.PAD_IDX] + \
+                      synth.text_to_tokens(t)[len(t) // 2:] + [TT.EOS_IDX, 3, 4]
+                ar[i, :len(row)] = row
+                al[i] = len(row)
+            ctc = ids.copy()
+            choice, scores = rerank_lm_batch(tables, torch.from_numpy(ar).to(dev), torch.from_numpy(al).to(dev),
+                                             torch.from_numpy(ctc).to(dev), torch.from_numpy(lens).to(dev))
+            choice, scores = choice.cpu().numpy(), scores.cpu().numpy()
+            for i, t in enumerate(texts):
+                want = float(lm.logp(t.strip())) - 0.002 * len(t.strip())
+                assert float(scores[i, 0]).hex() == want.hex() and float(scores[i, 1]).hex() == want.hex(), (order, S, i)
+                assert choice[i] == 0                                   # equal scores: the AR transcript stays
+
+
+def test_tables_with_a_value_that_is_not_finite_are_refused(dev):
+    """The bounds that drop candidates before their look-up rest on the range of the table values: a NaN or an
+    infinity in any log-prob is an error of nsd_tables_create, not a silent mis-prune."""
+    from silent_speech_amd import lib
+    from silent_speech_amd.decoder import DeviceTables
+    from silent_speech_amd.tables import HostTrie, compile_ngram, flatten_trie
+    words = ["ab", "ba"]
+    lm = O.NgramLM(3).fit(["ab ba ab", "ba ba"])
+    nodes = flatten_trie(HostTrie.from_words(words))
+    for field, bad in (("gram_recs", np.nan), ("ctxs", np.inf), ("grams", -np.inf)):
+        ng = compile_ngram(lm, None)
+        arr = getattr(ng, field)
+        name = "logp" if "logp" in arr.dtype.names else "term"
+        arr[name][np.flatnonzero(arr["key"] != np.uint64(0xFFFFFFFFFFFFFFFF))[0] if "key" in arr.dtype.names else 0] = bad
+        with pytest.raises(lib.NsdError, match="malformed table"):
+            DeviceTables(nodes, ng)
+    DeviceTables(nodes, compile_ngram(lm, None))                        # the untouched tables are fine
+
+
+def test_ar_step_kernels_refuse_misaligned_rows(dev):
+    from silent_speech_amd import lib
+    L = lib.load()
+    x = torch.zeros(4 * 64 + 8, dtype=torch.bfloat16, device=dev)
+    w = torch.ones(64, dtype=torch.bfloat16, device=dev)
+    h = torch.zeros(4 * 64, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.nsd_add_rmsnorm(x.data_ptr(), None, w.data_ptr(), 1e-5, 4, 64, 1, None, h.data_ptr(), st) == 0
+    assert L.nsd_add_rmsnorm(x.data_ptr() + 2, None, w.data_ptr(), 1e-5, 4, 64, 1, None, h.data_ptr(), st) == lib.E_ALIGN
+    g = torch.zeros(4 * 128 + 8, dtype=torch.bfloat16, device=dev)
+    assert L.nsd_swiglu(g.data_ptr(), 4, 64, 1, h.data_ptr(), st) == 0
+    assert L.nsd_swiglu(g.data_ptr() + 2, 4, 64, 1, h.data_ptr(), st) == lib.E_ALIGN
+    assert b"16 bytes" in L.nsd_strerror(lib.E_ALIGN)
+    torch.cuda.synchronize()
+
+
 def test_gather_ids_matches_host_histories(dev):
     from silent_speech_amd.decoder import DeviceTables, NSDecoder
     words = synth.make_lexicon(50, 1)

@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     lib.load()
-    assert lib.load().nsd_version() == 102
+    assert lib.load().nsd_version() == 103
     assert b"beam" in lib.load().nsd_strerror(-2)
     # the exported slot hash equals the table builder's
     for k in (0, 1, 12345678901234567, 2 ** 64 - 2):
