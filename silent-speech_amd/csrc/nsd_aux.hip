@@ -104,6 +104,15 @@ extern "C" int nsd_tables_create(const NsdTrieCSR *trie, const NsdNgramHash *lm,
     if ((e = hipMemcpy(t->nodes, trie->nodes, nb, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     t->n_nodes = trie->n_nodes;
     t->order = order;
+    {   // fan-out of the upper levels (nodes are numbered breadth-first): a tuning hint for nsd_step
+        const uint32_t top = trie->n_nodes < 1369u ? trie->n_nodes : 1369u;        // 1 + 36 + 36 * 37
+        uint64_t kids = 0, inner = 0;
+        for (uint32_t i = 0; i < top; ++i) {
+            const int c = __builtin_popcountll(trie->nodes[i].mask & ((1ull << NSD_NBASE) - 1));
+            if (c) { kids += (uint64_t)c; ++inner; }
+        }
+        t->fanout_x16 = inner ? (uint32_t)(16 * kids / inner) : 0u;
+    }
     if (order > 0) {
         const size_t gb = sizeof(NsdGramSlot) * (size_t)lm->gram_cap;
         const size_t cb = sizeof(NsdCtxSlot) * (size_t)lm->ctx_cap;

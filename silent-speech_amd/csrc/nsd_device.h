@@ -16,7 +16,7 @@ struct NsdTables {
     NsdGramRec  *gram_recs;      // automaton: seen n-grams grouped by context
     uint32_t     n_ctx_recs, n_gram_recs;
     uint32_t     init_ctx;       // automaton id of the empty surface's context, or NSD_CTX_NONE
-    uint32_t     pad;
+    uint32_t     fanout_x16;     // mean children per node with children over the trie's upper levels, in sixteenths
     double       unseen;
     uint64_t     ctx_sym_mask;   // keeps the last order-1 symbols of a packed context
     double       lm_start;       // LM sum of the empty surface: the '^' window, which exists for order 1 only

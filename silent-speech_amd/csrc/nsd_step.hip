@@ -145,6 +145,7 @@ struct GroupLds {
     NSD_D float *rowbuf() const { return reinterpret_cast<float *>(base + s_off); }
     NSD_D uint32_t *cInfo() const { return reinterpret_cast<uint32_t *>(base + i_off); }
     NSD_D uint32_t *total() const { return reinterpret_cast<uint32_t *>(base + t_off); }
+    NSD_D double &tauSeen() const { return *reinterpret_cast<double *>(base + t_off + 8u); }   // t_off is a multiple of 8
     uint32_t sidx_off;
     NSD_D uint32_t *sIdx() const { return reinterpret_cast<uint32_t *>(base + sidx_off); }
 };
@@ -241,7 +242,10 @@ static int nsd_step_group(int B, int N, int hint)
 // QUAD: a logits row is spread over 4 lanes (10 elements each) instead of 8, rows belong to hypotheses by position
 // (row slot h of a pass = hypothesis pass * RPP + h, no compaction of the live ones), and the first pass's rows are
 // requested together with the hypothesis state: for copies of the decoder whose hypotheses are (nearly) all live.
-template <int G, int VARIANT, int BT, int ORD, bool QUAD>
+// DENSE: the lexicon's fan-out makes steps whose candidates exceed the buffer the rule (a launcher's guess from the trie,
+// a tuning knob like G: both forms give the same bits).  Rows that emit after a sweep are then filtered by the sweep's
+// threshold before they write anything, and a 4-lanes-per-row pass is split into halves only when it does not fit.
+template <int G, int VARIANT, int BT, int ORD, bool QUAD, bool DENSE>
 NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
 {
     constexpr int UPW = 64 / G;                   // utterances per wave
@@ -342,7 +346,7 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
 
     // ---------------- phase 1: hypothesis state -> LDS ----------------
     bool my_live = false;
-    if (gl == 0) L.total()[0] = 0;
+    if (gl == 0) { L.total()[0] = 0; if (DENSE) L.tauSeen() = -__builtin_inf(); }
     if (act && gl < nbeams) {
         const uint32_t i = (uint32_t)u * (uint32_t)B + (uint32_t)gl;
         const uint32_t meta = ld_meta;
@@ -618,6 +622,8 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         red(std::integral_constant<int, 4>{});  red(std::integral_constant<int, 8>{});
         red(std::integral_constant<int, 16>{}); red(std::integral_constant<int, 32>{});
         const double tau = m;
+        // B candidates reach tau whatever follows: rows that emit later drop what cannot reach it (see the passes)
+        if (DENSE && want && gl == 0 && tau > L.tauSeen()) L.tauSeen() = tau;
         uint32_t n = 0, nsc = 0;
         for (uint32_t ch = 0; ch < chunks; ++ch) {
             const uint32_t i = ch * G + gl;
@@ -940,6 +946,13 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         }
         if (over) C = (uint32_t)keep;
         nsd_wave_sync();
+        if (DENSE) {                               // the B-th best key so far is a threshold for the rows that follow
+            if (over && keep == B && gl == 0) {
+                const double kth = L.cKey()[B - 1];
+                if (kth > L.tauSeen()) L.tauSeen() = kth;
+            }
+            nsd_wave_sync();
+        }
     };
 
     // finished hypotheses compete unchanged (ns_utils.py:222-224); they are scored with the first pass
@@ -1005,57 +1018,30 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         else nsd_row_log_softmax5(x);
 
         // With 4 lanes per row a pass covers twice the rows the buffer is sized for, and the fall-back's row
-        // buffer holds half of them: when the pass might overflow the buffer or has a fall-back row (both rare),
-        // its rows emit their candidates in two halves.
-        const bool split = QUAD && (may_overflow || __builtin_amdgcn_ballot_w64(fb) != 0);
-        const int nhalf = split ? 2 : 1;
+        // buffer holds half of them: when the pass has a fall-back row or might not fit the buffer (both rare
+        // unless the lexicon is dense), its rows emit their candidates in two halves; with a dense lexicon only
+        // once a pass turns out not to fit.
+        bool split = QUAD && ((!DENSE && may_overflow) || __builtin_amdgcn_ballot_w64(fb) != 0);
+        int nhalf = split ? 2 : 1;
 #pragma unroll 1
         for (int eh = 0; eh < nhalf; ++eh) {
-            const bool part = !split || (rslot / (RPP / 2)) == eh;
-            const uint64_t pmask = part ? mask : 0;
+            bool part = !split || (rslot / (RPP / 2)) == eh;
 
-            // the buffer must hold what these rows can add; otherwise prune it to its top-B first
-            if (may_overflow) {
-                uint32_t add = 0;
-                if (live && part && j == 0)
-                    add = fb ? (uint32_t)kfb + (eos_u ? 1u : 0u)
-                             : (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + ((eos_u || eos_e) ? 1u : 0u);
-#pragma unroll
-                for (int off = RL; off < G; off <<= 1) add += __shfl_xor(add, off);
-                add = __shfl(add, gshift);
-                bool over = act && C + add > CAP;
-                if (__builtin_amdgcn_ballot_w64(over && C > (uint32_t)G) != 0) {
-                    nsd_wave_sync();
-                    bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
-                    over = act && C + add > CAP;
-                }
-                if (__builtin_amdgcn_ballot_w64(over) != 0) {
-                    NSD_TIC();
-                    // score_new covers every group of the wave; when it does not run, the groups that are not
-                    // over keep their unscored tail
-                    if (__builtin_amdgcn_ballot_w64(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
-                    NSD_TOC(dbg_t_score);
-                    NSD_TIC();
-                    prune(over);
-                    NSD_TOC(dbg_t_prune);
-                    if (over) scored = C;
-                }
-            }
-
-            // lexicon-allowed characters: one prefix sum over the lanes' candidate counts places all of a lane's
-            // tokens (a ballot per token costs more, most of all with several utterances per wave).  The order of
-            // candidates in the buffer carries no meaning: ties are broken by the order field of the info word.
-            {
-                const uint32_t own = (uint32_t)((pmask & ((1ull << NSD_NBASE) - 1ull)) >> (j * EPL)) & ((1u << EPL) - 1u);   // this lane's tokens
-                const uint32_t n = (uint32_t)__popc(own);
-                uint32_t incl = n;
+            // this lane's lexicon-allowed tokens of its row
+            uint32_t own = part ? (uint32_t)((mask & ((1ull << NSD_NBASE) - 1ull)) >> (j * EPL)) & ((1u << EPL) - 1u) : 0u;
+            uint32_t n = 0, incl = 0, total = 0;
+            // One prefix sum over the lanes' candidate counts places all of a lane's tokens (a ballot per token costs
+            // more, most of all with several utterances per wave).  The order of candidates in the buffer carries no
+            // meaning: ties are broken by the order field of the info word.
+            auto count_own = [&]() {
+                n = (uint32_t)__popc(own);
+                incl = n;
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);         // row_shr:1
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);         // row_shr:2
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);         // row_shr:4
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);         // row_shr:8
                 if (G >= 32) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1, 3
                 if (G == 64) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2, 3
-                uint32_t total;
                 if (G == 64) {
                     total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 } else if (G == 32) {
@@ -1064,6 +1050,101 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
                 } else {
                     total = (uint32_t)__shfl((int)incl, gshift + G - 1);
                 }
+            };
+            if constexpr (!DENSE) {
+                // the buffer must hold what these rows can add; otherwise prune it to its top-B first
+                if (may_overflow) {
+                    uint32_t add = 0;
+                    if (live && part && j == 0)
+                        add = fb ? (uint32_t)kfb + (eos_u ? 1u : 0u)
+                                 : (uint32_t)__popcll(mask & ((1ull << NSD_NBASE) - 1)) + ((eos_u || eos_e) ? 1u : 0u);
+#pragma unroll
+                    for (int off = RL; off < G; off <<= 1) add += __shfl_xor(add, off);
+                    add = __shfl(add, gshift);
+                    bool over = act && C + add > CAP;
+                    if (__builtin_amdgcn_ballot_w64(over && C > (uint32_t)G) != 0) {
+                        nsd_wave_sync();
+                        bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
+                        over = act && C + add > CAP;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(over) != 0) {
+                        NSD_TIC();
+                        // score_new covers every group of the wave; when it does not run, the groups that are not
+                        // over keep their unscored tail
+                        if (__builtin_amdgcn_ballot_w64(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
+                        NSD_TOC(dbg_t_score);
+                        NSD_TIC();
+                        prune(over);
+                        NSD_TOC(dbg_t_prune);
+                        if (over) scored = C;
+                    }
+                }
+                count_own();
+            } else {
+                bool swept = false;
+#pragma unroll 1
+                for (;;) {
+                    if (may_overflow) {
+                        // Rows that emit after a sweep drop, before anything is written, the characters that cannot
+                        // reach the threshold the sweep established: B candidates with a key of at least that value
+                        // exist whatever follows, and the upper bound is the one the sweep itself would compute for
+                        // the candidate.
+                        const double tau_seen = L.tauSeen();
+                        const bool known = act && tau_seen > -__builtin_inf();
+                        if (__builtin_amdgcn_ballot_w64(known && own != 0) != 0) {
+                            if (known && own != 0) {
+                                const double sb = L.bScore(r), ge = L.bGe(r);
+                                const bool has_int = 1 + glen + 1 >= order, full_new = 1 + glen + 2 >= order;
+                                const double sub_hi = !(P.beta < 0.0) ? a.tab.max_logp : a.tab.min_logp;
+                                const double den = VARIANT == NSD_VARIANT_E ? P.len_denom[glen + 1] : 1.0;
+#pragma unroll
+                                for (int k = 0; k < EPL; ++k) {
+                                    if (j * EPL + k == (int)NSD_SPACE) continue;      // a space is its own (exact) bound
+                                    double hi = char_score(sb, (double)x[k], ge, has_int, sub_hi, full_new, sub_hi, use_lm, P.beta);
+                                    if (VARIANT == NSD_VARIANT_E) hi = hi / den;
+                                    if (hi < tau_seen) own &= ~(1u << k);
+                                }
+                            }
+                        }
+                    }
+                    count_own();
+                    if (!may_overflow) break;
+
+                    // the buffer must hold what these rows add (their characters, an EOS option each, the picks of a
+                    // fall-back row); otherwise it is swept, and pruned to its top-B if need be
+                    const uint32_t n_fb = (uint32_t)__popcll(gballot(fb && part && j == 0));
+                    const uint32_t n_eos = (uint32_t)__popcll(gballot(live && part && j == 0 && (eos_u || eos_e)));
+                    const uint32_t add = total + n_fb * (uint32_t)kfb + n_eos;
+                    const bool over = act && C + add > CAP;
+                    if (QUAD && !split && __builtin_amdgcn_ballot_w64(over) != 0) {
+                        split = true;                                  // the whole pass does not fit: first half now
+                        nhalf = 2;
+                        part = (rslot / (RPP / 2)) == eh;
+                        if (!part) own = 0;
+                        continue;
+                    }
+                    if (!swept && __builtin_amdgcn_ballot_w64(over && C > (uint32_t)G) != 0) {
+                        nsd_wave_sync();
+                        bound_prune(over && C > (uint32_t)G);          // cheap: no look-ups, no ranking
+                        swept = true;
+                        continue;                                      // these rows are filtered again with its threshold
+                    }
+                    if (__builtin_amdgcn_ballot_w64(over) != 0) {
+                        NSD_TIC();
+                        // score_new covers every group of the wave; when it does not run, the groups that are not
+                        // over keep their unscored tail
+                        if (__builtin_amdgcn_ballot_w64(over && scored < C) != 0) { nsd_wave_sync(); score_new(scored, false); nsd_wave_sync(); scored = C; }
+                        NSD_TOC(dbg_t_score);
+                        NSD_TIC();
+                        prune(over);
+                        NSD_TOC(dbg_t_prune);
+                        if (over) scored = C;
+                    }
+                    break;
+                }
+            }
+
+            {
                 uint32_t s = C + incl - n;
                 const bool room = C + incl <= CAP;               // all of this lane's tokens fit
                 if (!room && n) err_cap = true;
@@ -1242,7 +1323,7 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
     NSD_STAMP(5);
 }
 
-template <int G, int VARIANT, int BT, int ORD, bool QUAD>
+template <int G, int VARIANT, int BT, int ORD, bool QUAD, bool DENSE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 nsd_step_kernel(StepArgs a, NsdParams P)
 {
@@ -1250,12 +1331,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
     // Diagnostic build only: the whole step runs NSD_REPEAT times on the same input (the caller passes distinct
     // in / out states), so that stamps of the later runs show a wave's time with caches and translations warm.
     for (int rep = 0; rep < NSD_REPEAT; ++rep) {
-        nsd_step_body<G, VARIANT, BT, ORD, QUAD>(a, P, rep);
+        nsd_step_body<G, VARIANT, BT, ORD, QUAD, DENSE>(a, P, rep);
         __builtin_amdgcn_s_waitcnt(0);
         nsd_wave_sync();
     }
 #else
-    nsd_step_body<G, VARIANT, BT, ORD, QUAD>(a, P, 0);
+    nsd_step_body<G, VARIANT, BT, ORD, QUAD, DENSE>(a, P, 0);
 #endif
 }
 
@@ -1266,8 +1347,8 @@ extern "C" int nsd_debug_set_stamps(unsigned long long *p)
 }
 #endif
 
-template <int G, int VARIANT, int BT, int ORD, bool QUAD>
-static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+template <int G, int VARIANT, int BT, int ORD, bool QUAD, bool DENSE>
+static void launch_gvd(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     constexpr int UPW = 64 / G;
     const uint32_t lds_per_wave = a.lds_per_utt * UPW;
@@ -1284,11 +1365,23 @@ static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t 
     const long long n_waves = ((long long)N + UPW - 1) / UPW;
     const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
     if (ev0 || ev1)      // the events take the kernel's own start / end timestamps (no marker packets in between)
-        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD, QUAD>), dim3(grid), dim3(64 * waves),
+        hipExtLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD, QUAD, DENSE>), dim3(grid), dim3(64 * waves),
                               lds_fixed + lds_per_wave * (uint32_t)waves, s, ev0, ev1, 0, a, p);
     else
-        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD, QUAD>), dim3(grid), dim3(64 * waves),
+        hipLaunchKernelGGL((nsd_step_kernel<G, VARIANT, BT, ORD, QUAD, DENSE>), dim3(grid), dim3(64 * waves),
                            lds_fixed + lds_per_wave * (uint32_t)waves, s, a, p);
+}
+
+// Dense lexicon?  The trie's mean fan-out over its upper levels (NsdTables::fanout_x16, sixteenths) times the beam is
+// what a step emits when every hypothesis sits at such a node; beyond the candidate buffer the form that filters at
+// emission pays.  NSD_STEP_DENSE=0/1 in the environment overrides the guess (both forms give the same bits).
+template <int G, int VARIANT, int BT, int ORD, bool QUAD>
+static void launch_gv(const StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    static const int forced = [] { const char *e = getenv("NSD_STEP_DENSE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+    const bool dense = forced >= 0 ? forced == 1 : (uint64_t)a.tab.fanout_x16 * (uint64_t)a.B > 16ull * a.cap;
+    if (dense) launch_gvd<G, VARIANT, BT, ORD, QUAD, true>(a, p, N, s, ev0, ev1);
+    else       launch_gvd<G, VARIANT, BT, ORD, QUAD, false>(a, p, N, s, ev0, ev1);
 }
 
 // The instantiation for this call: beams 8, 16 and 32 with a 5-gram model (the shapes of the benchmark

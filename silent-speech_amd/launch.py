@@ -29,6 +29,8 @@ def rank_env(rank: int, world: int, port: int, base: Optional[dict] = None) -> d
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # RCCL shares buffers between the ranks of a node through IPC handles; hosts whose driver supports only dmabuf
+    # handles fail in the legacy mode ("hipIpcGetMemHandle: invalid argument").  A value already set wins.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
 
