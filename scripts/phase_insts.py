@@ -7,7 +7,7 @@ REPS times each on that same state and logits (the truncated kernels write nothi
 file by dispatch order and prints the differences.
 
   build:  python scripts/phase_insts.py build      (here, before the GPU call)
-  run:    python scripts/phase_insts.py run [variant] [utts] [beam] [step]
+  run:    python scripts/phase_insts.py run [variant] [utts] [beam] [step] [open]
 """
 import ctypes as C, subprocess, sys
 from pathlib import Path
@@ -37,8 +37,9 @@ variant = sys.argv[2] if len(sys.argv) > 2 else "I"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 BEAM = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 STEP = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+OPEN = len(sys.argv) > 6 and sys.argv[6] == "open"
 dev = torch.device("cuda", 0)
-words = S.make_lexicon(200, 0)
+words = S.make_lexicon(100000, 1, S.BASE_CHARS[:36], 2, 12) if OPEN else S.make_lexicon(200, 0)
 lm = NgramCounts(5, floor_vsz=(variant == "U")).fit(S.make_sentences(words, 20000, 1))
 tg, tl = S.pack_targets(S.targets_for_range(words, 0, N))
 tgd, tld = torch.from_numpy(tg).to(dev), torch.from_numpy(tl).to(dev)
