@@ -229,7 +229,12 @@ int nsd_state_init(const NsdTables *t, const NsdBeamState *st, int32_t N, int32_
  *   token    device [N*B] u8: appended token or NSD_TOKEN_CARRY (this step's slice)
  *   mask_dbg device [N*B] u64 or NULL: lexicon mask of each live parent
  * Utterances already NSD_U_DONE are left untouched.  N * B above NSD_MAX_HYPS
- * is refused with NSD_E_SIZE before anything is enqueued (split the batch). */
+ * is refused with NSD_E_SIZE before anything is enqueued (split the batch).
+ * The launcher picks among several forms of the kernel (lanes per utterance, compile-time beam / n-gram order for
+ * beams 8, 16, 32 with a 5-gram model, 4 lanes per logits row for the copy without an EOS option, a form for dense
+ * lexicons chosen from the trie's fan-out); all give the same bits.  Two environment variables restrict the choice
+ * for debugging, read once per process: NSD_STEP_MODE (0 = run-time form only, 1 = no 4-lanes-per-row form) and
+ * NSD_STEP_DENSE (0 / 1 = never / always the dense-lexicon form). */
 int nsd_step(const NsdTables *t, const NsdParams *p, const float *logits,
              const NsdBeamState *in, const NsdBeamState *out,
              uint8_t *backptr, uint8_t *token, uint64_t *mask_dbg,
