@@ -15,11 +15,11 @@ A = synth.BASE_CHARS[:36]
 dense = ["".join(p) for n in (1, 2) for p in itertools.product(A, repeat=n)] + ["".join(p) for p in itertools.product(A[:8], A, A)]
 k = 0
 for variant in "UIE":
-    for beam in (16, 32, 40, 64):
+    for beam in (8, 16, 32, 40, 64):
         if variant != "U" and beam > 40:
             continue
         for lanes in sorted({0, 64, 16 if beam <= 16 else (32 if beam <= 32 else 64)}):
-            case = dict(variant=variant, beam=beam, lm_order=rng.choice([0, 2, 3]), beta=0.1, margin=rng.choice([0.0, 1.0]),
+            case = dict(variant=variant, beam=beam, lm_order=rng.choice([0, 2, 3, 5, 5]), beta=0.1, margin=rng.choice([0.0, 1.0]),
                         gamma=1.0, kappa=0.35, alpha=0.6, min_len_for_eos=2, max_new_tokens=10, n_words=3, lex_seed=1,
                         max_len=3, n_corpus=200, corpus_seed=3, n_utts=96, target_seed=5, base_seed=rng.randrange(1 << 30),
                         min_words=1, max_words=3, alphabet=A, extra_words=dense, lanes=lanes, name=f"dense{k}")

@@ -26,6 +26,9 @@ def test_random_cases_with_one_form_forced(dense):
     assert out.returncode == 0 and "all 120 cases equal" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     out = _run(["scripts/fuzz_parity.py", "80", "4242", "-1", "hot"], dense)
     assert out.returncode == 0 and "all 80 cases equal" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # a lexicon in which every node has all 36 children, wide beams, flat logits: every pass overflows the buffer
+    out = _run(["scripts/fuzz_dense.py", "21"], dense)
+    assert out.returncode == 0 and "dense cases equal" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("dense", ["0", "1"])
