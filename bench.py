@@ -678,7 +678,11 @@ def worker(args):
                                 "closed 200-word template lexicon") +
                                f", {shape}, beam {args.beam}, char {args.order}-gram, "
                                f"variant {args.variant} ({VARIANT_SRC[args.variant]}), beta {args.beta}, gamma {args.gamma}, "
-                               f"margin {args.margin}, T_max {args.tmax}",
+                               f"margin {args.margin}, T_max {args.tmax}" +
+                               ("; this copy of the decoder has no EOS option and decodes all T_max steps whatever the "
+                                "target's length, so `value` counts the characters after the target's end too "
+                                f"({100.0 * (1.0 - target_chars / max(chars, 1.0)):.0f} % of them here): "
+                                "target_chars_per_s is the transcript throughput" if args.variant == "I" else ""),
                    "utterances_total": n_total, "utterances_per_rank": [int(x) for x in per_rank.tolist()],
                    "ranks_reported_by_process_group": dist.get_world_size() if grouped else 1,
                    "process_group": (dist.get_backend() if grouped else None),
