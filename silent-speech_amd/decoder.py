@@ -315,6 +315,20 @@ def clear_table_cache() -> None:
 _WS_CACHE: "OrderedDict[tuple, Workspace]" = OrderedDict()
 
 
+_HOST_BUFS: dict = {}
+
+
+def _host_buffers(B: int):
+    """Pinned host buffers of the drop-in entry point for beam B: logits rows [B, 40] and the step's outcome."""
+    b = _HOST_BUFS.get(B)
+    if b is None:
+        if len(_HOST_BUFS) > 8:
+            _HOST_BUFS.clear()
+        b = _HOST_BUFS[B] = (torch.zeros(B, VOCAB, dtype=torch.float32).pin_memory(),
+                             torch.zeros(2 * B + 4, dtype=torch.uint8).pin_memory())
+    return b
+
+
 def _workspace_for(dec: "NSDecoder") -> "Workspace":
     """One-utterance workspace of the drop-in entry point, kept per (beam, steps, device): a call per utterance
     re-initialises its 18 device buffers instead of allocating them again."""
@@ -377,9 +391,16 @@ def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, l
     # inference_emg_llm.py:281): that happens right after step_fn was called for the first hypothesis without a
     # lexicon-consistent option, so the remaining hypotheses of the step are never evaluated
     raises_on_fallback = B > VOCAB and variant != "U"
+    # Host side of a step: rows that step_fn returns on the host are collected in one pinned buffer and cross to the
+    # device in one copy (rows it returns on a device are copied there directly); the step's outcome (utterance word,
+    # back-pointers, tokens) comes back in one read.  Rows of hypotheses that are not live are never read by the
+    # kernel, so the buffers keep whatever they held.
+    rows, back = _host_buffers(B)
+    rows_np = rows.numpy()
+    logits = ws.logits
     for t in range(dec.T):
-        rows = torch.zeros(B, VOCAB, dtype=torch.float32)
         dev_rows = []
+        any_host = False
         if raises_on_fallback:
             meta_h = ws.meta[:len(hyps)].tolist()
             node_h = ws.node[:len(hyps)].tolist()
@@ -392,19 +413,27 @@ def constrained_beam_decode(step_fn, TT, beam: int, max_new_tokens: int, trie, l
                 mask = 0 if dead else int(tables.nodes["mask"][node_h[r]])
                 if mask & ((1 << 37) - 1) == 0:
                     raise RuntimeError("selected index k out of range")
-            dev_rows.append((r, out.detach().reshape(-1).to(dtype=torch.float32)))
-        logits = rows.to(dec.device)
+            v = out.detach().reshape(-1)
+            if v.device.type == "cpu":
+                rows_np[r] = v.numpy() if v.dtype == torch.float32 else v.to(torch.float32).numpy()
+                any_host = True
+            else:
+                dev_rows.append((r, v))
+        if any_host:
+            logits.copy_(rows, non_blocking=True)
         for r, v in dev_rows:
-            logits[r] = v.to(dec.device)
+            logits[r].copy_(v)
         dec.step(ws, logits)
-        um = int(ws.utt[0].item())
+        back.copy_(torch.cat((ws.backptr[t, :B], ws.token[t, :B], ws.utt[:1].view(torch.uint8))))     # one read, synchronises
+        raw = back.numpy()
+        um = int.from_bytes(raw[2 * B:2 * B + 4].tobytes(), "little")
         if um & _lib.U_ERR_INTERNAL:
             raise _lib.NsdError("nsd_step reported an overflowing candidate buffer (a defect of the library)")
         if um & _lib.U_ERR_TOPK:
             raise RuntimeError("selected index k out of range")
         nb = um & 0xFF
-        par = ws.backptr[t, :nb].tolist()
-        tok = ws.token[t, :nb].tolist()
+        par = raw[:nb].tolist()
+        tok = raw[B:B + nb].tolist()
         hyps = [hyps[p] if k == _lib.TOKEN_CARRY else hyps[p] + [k] for p, k in zip(par, tok)]
         if um & _lib.U_DONE:
             break
