@@ -48,8 +48,9 @@ def test_noalloc_decode_equals_the_workspace_decode(variant):
                                         out_sc.data_ptr(), st)
         assert rc == 0, lib.load().nsd_strerror(rc)
         torch.cuda.synchronize()
-        if k > 0:
-            assert torch.cuda.mem_get_info()[0] == free_before           # no device memory taken by the call
+        # no device memory taken by the call, the first one included: the scratch address was resolved when the
+        # tables were created, and the decode just above has loaded the kernels
+        assert torch.cuda.mem_get_info()[0] == free_before
         la, lb = lens_a.cpu().numpy(), out_len.cpu().numpy()
         assert (la == lb).all(), (variant, k)
         ia, ib = ids_a.cpu().numpy(), out_ids.cpu().numpy()
