@@ -414,7 +414,8 @@ nsd_lm_logp_kernel(NsdTables tab, const uint8_t *text, const int32_t *len, int N
     double *vals = reinterpret_cast<double *>(lm_smem + (size_t)wid * (512 + buf_bytes));
     uint8_t *buf = reinterpret_cast<uint8_t *>(vals + 64);
     const uint8_t *s = text + (size_t)u * stride;
-    const int b = len[u];
+    int b = len[u];
+    b = b < 0 ? 0 : (b > stride ? stride : b);     // a length beyond the row would run past the LDS buffer
     for (int i = lane; i < b; i += 64) buf[i] = s[i];
     nsd_wave_sync();
     if (b == 0) { if (lane == 0) out[u] = -1e9; return; }
@@ -513,9 +514,11 @@ nsd_rerank_lm_kernel(NsdTables tab, const uint8_t *ar_ids, const int32_t *ar_len
     const int u = blockIdx.x;
     double *vals = reinterpret_cast<double *>(lm_smem + (size_t)wid * (512 + buf_bytes));
     uint8_t *buf = reinterpret_cast<uint8_t *>(vals + 64);
+    // (lengths are held to their rows: the compacted characters of a row must fit the LDS buffer)
+    const int na = ar_len[u] < ar_stride ? ar_len[u] : ar_stride, nc = ctc_len[u] < ctc_stride ? ctc_len[u] : ctc_stride;
     const double sc = wid == 0
-        ? nsd_wave_hyp_lm_score(tab, ar_ids + (size_t)u * ar_stride, ar_len[u], true, buf, vals, lane)
-        : nsd_wave_hyp_lm_score(tab, ctc_ids + (size_t)u * ctc_stride, ctc_len[u], false, buf, vals, lane);
+        ? nsd_wave_hyp_lm_score(tab, ar_ids + (size_t)u * ar_stride, na, true, buf, vals, lane)
+        : nsd_wave_hyp_lm_score(tab, ctc_ids + (size_t)u * ctc_stride, nc, false, buf, vals, lane);
     if (lane == 0) both[wid] = sc;
     __syncthreads();
     if (threadIdx.x == 0) {
