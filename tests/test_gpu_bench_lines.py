@@ -45,6 +45,16 @@ def test_default_line_with_its_blocks():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["transcript_mismatches_vs_gpu"] == 0
 
 
+def test_open_lexicon_line():
+    d = _line([sys.executable, "bench.py", "--open-lexicon", "--lex-words", "5000", "--beam", "32", "--utts", "128",
+               "--steps", "2", "--warmup", "1", "--timed-decodes", "1", "--cpu-utts", "2", "--cpu-seconds", "30",
+               "--cpu-seconds-all", "0", "--also="])
+    assert d["config"]["workload"].startswith("configs[2]") and "beam 32" in d["metric"]
+    _check_roofline(d["roofline"])
+    assert d["roofline"]["mean_children_per_live_hyp"] > 8          # a dense lexicon: many children per hypothesis
+    assert d["cpu_baseline"]["transcript_mismatches_vs_gpu"] == 0
+
+
 def test_ctc_rerank_line():
     d = _line([sys.executable, "bench.py", "--ctc-rerank", *SMALL])
     for k in CONTRACT:
