@@ -228,11 +228,17 @@ NSD_D GroupLds carve(unsigned char *base, int B, uint32_t cap, bool with_score)
 // Lanes per utterance.  A wave carries 64/G utterances: narrow groups cut the instructions per utterance
 // when few hypotheses are live, but serialise an utterance's rows over more passes, which only pays once
 // the launch has far more waves than the chip holds at a time.
-static int nsd_step_group(int B, int N, int hint)
+static int nsd_step_group(int B, int N, int hint, int variant)
 {
     const int gmin = B <= 16 ? 16 : (B <= 32 ? 32 : 64);
     if (hint == 16 || hint == 32 || hint == 64) return hint < gmin ? gmin : hint;
-    return N >= 16384 ? (gmin < 32 ? 32 : gmin) : 64;
+    // measured at beam 16: two utterances per wave win from 16 384 utterances on for the copy without an EOS option
+    // (all hypotheses live: 57.1 against 59.8 us at 24 576, 37.9 against 35.0 us at 12 288), from 8 192 on for the
+    // copy that offers EOS at every step (few live hypotheses: 14.8 against 15.3 us at 8 192, 21.2 against 24.5 us at
+    // 16 384), and only beyond 65 536 for the length-normalised copy (115.6 against 112.2 us at 65 536, 239.0 against
+    // 244.6 us at 131 072)
+    const int many = variant == NSD_VARIANT_U ? 8192 : (variant == NSD_VARIANT_E ? 98304 : 16384);
+    return N >= many ? (gmin < 32 ? 32 : gmin) : 64;
 }
 
 
@@ -1417,7 +1423,7 @@ static void launch_shape(const StepArgs &a, const NsdParams &p, int N, hipStream
 template <int VARIANT>
 static void launch_variant(StepArgs &a, const NsdParams &p, int N, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    const int G = nsd_step_group(a.B, N, p.lanes_per_utt);
+    const int G = nsd_step_group(a.B, N, p.lanes_per_utt, p.variant);
     a.cap = step_cap(a.B, G, p.variant);
     a.lds_per_utt = step_lds_per_utt(a.B, G, p.variant);
     {   // staged trie records: what was asked for, within the trie, the documented maximum and a workgroup's LDS
