@@ -968,7 +968,10 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
 
     // ---------------- passes: log-softmax, candidates, scores ----------------
     const int npass = act ? ((QUAD ? nbeams : nlive) + RPP - 1) / RPP : 0;
-    const int npass_max = (int)wave_max((uint32_t)npass);
+    // with rows by position and a beam that one pass covers, the loop below runs at most once: the instantiation
+    // knows it (no next-pass request, no copy of the requested row)
+    constexpr bool ONE_PASS = QUAD && BT > 0 && BT <= RPP;
+    const int npass_max = ONE_PASS ? (wave_max((uint32_t)npass) != 0u ? 1 : 0) : (int)wave_max((uint32_t)npass);
     auto fetch_row = [&](int pass) {
         const int slot = pass * RPP + rslot;
         if (act && slot < (QUAD ? nbeams : nlive)) {
@@ -1018,7 +1021,7 @@ NSD_D void nsd_step_body(const StepArgs &a, const NsdParams &P, const int rep)
         float x[EPL];
 #pragma unroll
         for (int k = 0; k < EPL; ++k) x[k] = xn[k];
-        if (pass + 1 < npass_max) fetch_row(pass + 1);
+        if (!ONE_PASS && pass + 1 < npass_max) fetch_row(pass + 1);
         if (pass == 0) NSD_STAMP(6);
         if constexpr (QUAD) nsd_row_log_softmax10(x);
         else nsd_row_log_softmax5(x);
