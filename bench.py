@@ -468,6 +468,9 @@ def large_batch(args, words, corpus, n_utts, dev):
     d = timed_launches(dec, ws, tgd, tld, a2, 2)
     T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, a2)
     r = roofline_of(per_step, live, cands, d, steps_run)
+    r["traffic"], src = profiled_traffic(a2)
+    if src:
+        r["traffic_note"] = f"from the separate rocprofv3 --pmc passes kept in {src} (same build, not this run)"
     return {"workload": f"{n_utts} utterances on one GPU, otherwise as the main line (variant {args.variant}, beam "
                         f"{args.beam}, char {args.order}-gram, T_max {args.tmax})",
             "value": float(nchar.sum()) * reps / dt, "unit": "chars/s", "decodes": reps,
@@ -475,6 +478,27 @@ def large_batch(args, words, corpus, n_utts, dev):
             "targets_recovered_as_prefix": int(starts.sum()),
             "target_chars_per_s": float(tl[starts].sum()) * reps / dt,
             "roofline": r}
+
+
+def profiled_traffic(args):
+    """HBM-side bytes per nsd_step launch for this workload, if separate rocprofv3 --pmc passes of this very command
+    are kept under profiles/ (FETCH_SIZE and WRITE_SIZE in runs of their own, FETCH_SIZE doubled: the gfx950 correction
+    for wide coalesced reads; scripts/pmc_traffic.sh, scripts/collect_traffic.py).  The counters cannot be read from
+    inside this process, so the figure is the one those passes measured on the same build, not a live one."""
+    if not (args.variant == "I" and args.beam == 16 and args.order == 5 and args.tmax == 64 and args.margin == 60.0
+            and args.beta == 0.05 and args.gamma == 1.0 and args.lanes == 0 and args.lds_trie == 0) and \
+            not (args.open_lexicon and args.beam == 32):
+        return None, None
+    if args.open_lexicon:
+        name = "r03_pmc_traffic_open_lexicon_b32.json" if (args.beam == 32 and args.utts == 4096 and
+                                                          args.lex_words == 100000 and args.variant == "I") else None
+    else:
+        name = {4096: "r03_pmc_traffic.json", 131072: "r03_pmc_traffic_131072.json"}.get(args.utts) \
+            if args.lex_words == 200 else None
+    f = ROOT / "profiles" / name if name else None
+    if f is None or not f.exists():
+        return None, None
+    return float(json.loads(f.read_text())["traffic_bytes_per_launch"]), f"profiles/{name}"
 
 
 def parse_args(argv=None):
@@ -709,9 +733,14 @@ def worker(args):
         d = timed_launches(dec, ws, tgd, tld, args, args.timed_decodes)
         T, live, cands, per_step = algorithmic_bytes(dec, tgd, tld, args)
         result["roofline"] = roofline_of(per_step, live, cands, d, steps_run)
-        result["roofline"]["traffic_note"] = ("HBM-side bytes need separate rocprofv3 --pmc passes and are not "
-                                              "measured in this run; see profiles/ for the passes taken on this "
-                                              "command")
+        traffic, src = profiled_traffic(args)
+        result["roofline"]["traffic"] = traffic
+        result["roofline"]["traffic_note"] = (
+            f"HBM-side bytes per launch from the separate rocprofv3 --pmc passes kept in {src} (FETCH_SIZE and "
+            f"WRITE_SIZE in runs of their own on this command, FETCH_SIZE doubled as the gfx950 correction): measured "
+            f"on this build, not in this run" if src else
+            "HBM-side bytes need separate rocprofv3 --pmc passes and are not measured in this run; see profiles/ for "
+            "the passes taken on the benchmark commands")
     if args.also and args.also != args.variant and world == 1:
         result["variant_" + args.also] = secondary_variant(args, args.also, words, corpus, tgd, tld, tg, tl)
     if args.large_utts > args.utts and world == 1 and not args.open_lexicon:
