@@ -1,3 +1,4 @@
+// Build: hipcc -O2 --offload-arch=gfx950 scripts/clockcal.hip -o /tmp/clockcal
 // Calibration: shader-clock ticks (s_memtime) against the constant 100 MHz counter (s_memrealtime) inside short kernels.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
