@@ -107,6 +107,16 @@ def scored_cases():
                         n_corpus=20000, corpus_seed=1, n_utts=16, target_seed=1004, min_words=2, max_words=5,
                         base_seed=78, margin=4.0, beta=0.1, gamma=1.0, kappa=0.35, alpha=0.6,
                         min_len_for_eos=8))
+    # the drivers' own argument defaults (inference_emg_llm.py:313-321: beam 6, 128 steps, 3-gram, weight 0.3, penalty
+    # 1.0; eval_ar.py:370-383: beam 6, 64 steps, word bonus 0.35, alpha 0.6, EOS from 8 characters) on a lexicon with
+    # phrasebook lines (literal space edges), targets long enough to fill the 128 steps
+    for v, T in (("U", 128), ("I", 128), ("E", 64)):
+        out.append(dict(name=f"driver_{v}_b6", variant=v, beam=6, lm_order=3, max_new_tokens=T,
+                        n_words=200, lex_seed=0, min_len=2, max_len=8,
+                        extra_words=["new york", "thank you", "good morning", "ice cream"],
+                        n_corpus=20000, corpus_seed=1, n_utts=16, target_seed=1005,
+                        min_words=10 if T == 128 else 3, max_words=18 if T == 128 else 7, base_seed=79,
+                        margin=12.0, beta=0.3, gamma=1.0, kappa=0.35, alpha=0.6, min_len_for_eos=8))
     return out
 
 

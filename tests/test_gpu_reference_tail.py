@@ -26,7 +26,7 @@ def _pack(targets):
     return tg, np.array([len(t) for t in toks], np.int32)
 
 
-@pytest.mark.parametrize("idx", range(18))
+@pytest.mark.parametrize("idx", range(21))
 def test_reference_ids_and_scores_at_benchmark_sizes(golden_tail, idx):
     from silent_speech_amd import TextTransform
     from silent_speech_amd.decoder import DeviceTables, NSDecoder, ids_to_text

@@ -15,7 +15,7 @@ from tests.golden_util import case_model, case_targets, ctc_frames, decode_kwarg
 TT = O.TextTransformLike
 
 
-@pytest.mark.parametrize("idx", range(18))
+@pytest.mark.parametrize("idx", range(21))
 def test_scores_and_beam_indices_at_benchmark_sizes(golden_tail, idx):
     """64 utterances of the benchmark workload per copy and beam width: ids, transcript, the fp64 score of the
     returned hypothesis (bit for bit: same torch log-softmax, same operation order), the whole step_fn call
