@@ -19,7 +19,8 @@ for variant in "UIE":
         if variant != "U" and beam > 40:
             continue
         for lanes in sorted({0, 64, 16 if beam <= 16 else (32 if beam <= 32 else 64)}):
-            case = dict(variant=variant, beam=beam, lm_order=rng.choice([0, 2, 3, 5, 5]), beta=0.1, margin=rng.choice([0.0, 1.0]),
+            case = dict(variant=variant, beam=beam, lm_order=rng.choice([0, 2, 3, 5, 5]), beta=rng.choice([0.1, 0.1, 0.3, -0.3]),
+                        margin=rng.choice([0.0, 1.0]),
                         gamma=1.0, kappa=0.35, alpha=0.6, min_len_for_eos=2, max_new_tokens=10, n_words=3, lex_seed=1,
                         max_len=3, n_corpus=200, corpus_seed=3, n_utts=96, target_seed=5, base_seed=rng.randrange(1 << 30),
                         min_words=1, max_words=3, alphabet=A, extra_words=dense, lanes=lanes, name=f"dense{k}")
