@@ -1345,6 +1345,12 @@ nsd_step_kernel(StepArgs a, NsdParams P)
         nsd_wave_sync();
     }
 #else
+    // The workgroups that are resident when a launch starts (four per CU) would run their phases in step, the four
+    // waves of a SIMD asking for the vector unit at the same moments and waiting for memory at the same moments.
+    // The second half of them starts 1 024 cycles late (measured: 16.2 -> 16.0 us per launch at 4 096 utterances,
+    // 10.8 -> 10.65 us for the copy with an EOS option, nothing at other launch sizes; delays of 320-1 536 cycles
+    // spread over four groups do the same, 2 560 cycles and groupings that do not follow the dispatch order lose).
+    if (blockIdx.x >= 512u && blockIdx.x < 1024u) __builtin_amdgcn_s_sleep(16);
     nsd_step_body<G, VARIANT, BT, ORD, QUAD, DENSE>(a, P, 0);
 #endif
 }
