@@ -438,6 +438,40 @@ def ctc_rerank_workload(args, dev):
     return result
 
 
+def shards_in_flight(args, dec, tgd, tld, ids_ref, lens_ref, chars, target_chars, dev, shards=2):
+    """The same utterances decoded as `shards` halves on streams of their own (each shard's launches enqueued by
+    nsd_decode_synth on its stream): a launch lasts as long as its slowest wave, and the other shard's launches
+    fill that tail.  Reported beside `value`, which stays the one-stream decode whose launch the roofline describes."""
+    import torch
+    n = tgd.shape[0]
+    bounds = [(n * k // shards, n * (k + 1) // shards) for k in range(shards)]
+    wss = [dec.workspace(hi - lo) for lo, hi in bounds]
+    streams = [torch.cuda.Stream(device=dev) for _ in bounds]
+
+    def once():
+        for (lo, hi), w, st in zip(bounds, wss, streams):
+            with torch.cuda.stream(st):
+                dec.decode_synth_native(tgd[lo:hi], tld[lo:hi], base_seed=args.seed, margin=args.margin,
+                                        utt0=args.utt0 + lo, check_every=args.check_every, ws=w)
+
+    torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        once()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ids = torch.cat([w.out_ids[:hi - lo] for (lo, hi), w in zip(bounds, wss)])
+    lens = torch.cat([w.out_len[:hi - lo] for (lo, hi), w in zip(bounds, wss)])
+    same = bool(torch.equal(ids, ids_ref) and torch.equal(lens, lens_ref))
+    return {"shards": shards, "value": chars * args.steps / dt, "unit": "chars/s",
+            "target_chars_per_s": target_chars * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+            "equal_to_the_one_stream_decode": same,
+            "note": "same utterances, same kernels, two half-batches on two streams of one GPU"}
+
+
 def large_batch(args, words, corpus, n_utts, dev):
     """The same decode at a batch that fills the GPU many times over (one GPU's share of the 1M-utterance
     configuration): chars/s and the nsd_step roofline, with the fields of the main line."""
@@ -540,6 +574,10 @@ def parse_args(argv=None):
                                                          "choice; 16, 32 or 64)")
     ap.add_argument("--lds-trie", type=int, default=0, help="node records of the upper trie levels every workgroup "
                                                             "stages in LDS (0 = none, the default)")
+    ap.add_argument("--shards-in-flight", type=int, default=0,
+                    help="also time the same decode as this many shards on streams of their own (one GPU; e.g. 2); "
+                         "`value` stays the one-stream decode.  Off by default: the shards' launches run the same "
+                         "kernel instantiation, so a kernel trace of the command would average them into its row")
     ap.add_argument("--large-utts", type=int, default=131072,
                     help="utterances of the large_batch block measured after the main line on one GPU (0 = skip)")
     ap.add_argument("--ctc-rerank", action="store_true",
@@ -741,6 +779,10 @@ def worker(args):
             f"on this build, not in this run" if src else
             "HBM-side bytes need separate rocprofv3 --pmc passes and are not measured in this run; see profiles/ for "
             "the passes taken on the benchmark commands")
+    if args.shards_in_flight > 1 and world == 1 and args.utts >= 2 * args.shards_in_flight:
+        result["two_shards_in_flight" if args.shards_in_flight == 2 else "shards_in_flight"] = shards_in_flight(
+            args, dec, tgd, tld, ws.out_ids[:args.utts], ws.out_len[:args.utts], chars, target_chars, dev,
+            args.shards_in_flight)
     if args.also and args.also != args.variant and world == 1:
         result["variant_" + args.also] = secondary_variant(args, args.also, words, corpus, tgd, tld, tg, tl)
     if args.large_utts > args.utts and world == 1 and not args.open_lexicon:

@@ -32,9 +32,11 @@ def _check_roofline(r):
 
 
 def test_default_line_with_its_blocks():
-    d = _line([sys.executable, "bench.py", *SMALL, "--large-utts", "1024"])
+    d = _line([sys.executable, "bench.py", *SMALL, "--large-utts", "1024", "--shards-in-flight", "2"])
     for k in CONTRACT:
         assert k in d, k
+    two = d["two_shards_in_flight"]                # the same utterances as two half-batches on two streams
+    assert two["shards"] == 2 and two["equal_to_the_one_stream_decode"] is True and two["value"] > 0
     assert d["unit"] == "chars/s" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["config"]["workload"].startswith("configs[1]") and d["value"] > 0 and d["target_chars_per_s"] > 0
     _check_roofline(d["roofline"])
